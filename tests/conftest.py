@@ -1,0 +1,54 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "path-tracer_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def textures():
+    """The two images the reference host loads (GLSL_Renderer.cpp:237,240), decoded
+    to 8-bit arrays with rows top-to-bottom, exactly as stb_image hands them over."""
+    from PIL import Image
+    bg = np.array(Image.open(os.path.join(GOLDEN, "assets", "Background.png")))
+    tx = np.array(Image.open(os.path.join(GOLDEN, "assets", "Texture.png")))
+    assert bg.shape == (2048, 4096, 4) and tx.shape == (1080, 1920, 3)
+    return {"hdri": bg, "albedo": tx}
+
+
+@pytest.fixture(scope="session")
+def oracle_builtin(textures):
+    import kloracle as ko
+    sc = ko.Scene(builtin=True)
+    sc.set_texture(ko.TEX_HDRI, textures["hdri"])
+    sc.set_texture(ko.TEX_ALBEDO, textures["albedo"])
+    return sc
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def frac_within_rel(a, ref, tol=1e-4, floor=1e-6):
+    """fraction of pixels whose worst channel is within tol relative error"""
+    d = np.abs(a.astype(np.float64) - ref.astype(np.float64))
+    rel = d / np.maximum(np.abs(ref.astype(np.float64)), floor)
+    if rel.ndim == 3:
+        rel = rel.max(-1)
+    return float(np.mean(rel <= tol))
+
+
+def mae_clamped(a, ref):
+    """mean absolute error of what reaches the screen: PostProcess.glsl:38 writes the
+    accumulation texel to a UNORM backbuffer, i.e. clamp(x, 0, 1)"""
+    return float(np.mean(np.abs(np.clip(a, 0, 1).astype(np.float64) - np.clip(ref, 0, 1).astype(np.float64))))
