@@ -1,0 +1,207 @@
+/*
+ * kl_render.h -- C ABI of the MI355X path-tracing backend.
+ *
+ * This is the surface a host application binds in place of the OpenGL render
+ * dispatch of the reference (source/Rendering/Opengl/GLSL_Renderer.cpp:201-240
+ * set-up, :281-348 per-frame passes). Each entry point cites the reference
+ * interface it replaces. Plain C types only; every function returns a
+ * kl_status (0 = KL_OK, negative = error) and never throws.
+ *
+ * Ownership and threading: a kl_ctx is created and destroyed by the caller,
+ * owns one HIP device + stream, and must be used from one thread at a time
+ * (the reference drives everything from the thread that owns the GL context,
+ * GLSL_Renderer.cpp:243-359). Input pointers are borrowed for the duration of
+ * the call. Work is queued on the context's stream; the read/resolve/copy
+ * entry points and kl_synchronize wait for it.
+ */
+#ifndef KL_RENDER_H
+#define KL_RENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define KL_API __attribute__((visibility("default")))
+#else
+#define KL_API
+#endif
+
+typedef int32_t kl_status;
+enum {
+    KL_OK = 0,
+    KL_E_INVALID = -1,      /* bad argument */
+    KL_E_DEVICE = -2,       /* HIP runtime error (kl_last_error has the text) */
+    KL_E_NOMEM = -3,
+    KL_E_STATE = -4,        /* call not valid in the current state (e.g. no scene) */
+    KL_E_LIMIT = -5         /* size beyond a documented maximum */
+};
+
+/* view modes: Render_Mode::Enum, include/Rendering/Opengl/GLSL_Renderer.h:15-21;
+ * uploaded as iRenderMode, GLSL_Renderer.cpp:290 */
+enum { KL_MODE_AO = 0, KL_MODE_PT = 1, KL_MODE_Z = 2 };
+/* material types: resources/Shaders/RawFrame.glsl:126-129 */
+enum { KL_DIFFUSE = 0, KL_GLASS = 1, KL_EMISSIVE = 2, KL_TEXTURED = 3 };
+/* sampler slots: iHdri (unit 2) and iAlbedo (unit 3), GLSL_Renderer.cpp:301-304 */
+enum { KL_TEX_HDRI = 0, KL_TEX_ALBEDO = 1 };
+/* present pass: PostProcess.glsl:38 (CLAMP) or its overwritten lines 19-37 (ACES) */
+enum { KL_TONEMAP_CLAMP = 0, KL_TONEMAP_ACES = 1 };
+/* accumulation: running mean of Accumulation.glsl:16-24, or a plain sum for sample-range sharding */
+enum { KL_ACCUM_MEAN = 0, KL_ACCUM_SUM = 1 };
+/* intersection back end: brute force in declaration order (what RawFrame.glsl:294-328 does) or the SAH BVH */
+enum { KL_ACCEL_AUTO = 0, KL_ACCEL_BRUTE = 1, KL_ACCEL_BVH = 2 };
+#define KL_CONTINUE 0xFFFFFFFFu
+
+/* the camera uniforms iCameraPos/Front/Up/FocalLength/SensorWidth,
+ * RawFrame.glsl:9-13, uploaded at GLSL_Renderer.cpp:293-297 (already narrowed to float) */
+typedef struct kl_camera {
+    float pos[3], front[3], up[3];
+    float focal, sensor;
+} kl_camera;
+
+/* the shader's five-field material, RawFrame.glsl:131-137 (32 bytes) */
+typedef struct kl_material {
+    int32_t type;
+    float color[3];
+    float emissive;
+    float roughness;
+    float ior;
+    float pad;
+} kl_material;
+
+/* scene upload records shaped after include/Object/Sphere.h:6-12 and
+ * include/Object/Mesh.h:5-18 (Tri, Quad), carrying a material index */
+typedef struct kl_sphere { float center[3]; float radius; uint32_t material; } kl_sphere;
+typedef struct kl_quad { float v0[3], v1[3], v2[3], v3[3]; uint32_t material; } kl_quad;
+typedef struct kl_tri { float v0[3], v1[3], v2[3]; float uv0[2], uv1[2], uv2[2]; uint32_t material; } kl_tri;
+
+/* the shader's compile-time defines (RawFrame.glsl:32-40) as run-time parameters */
+typedef struct kl_params {
+    uint32_t max_bounces;      /* RAY_BOUNCES, 32 */
+    uint32_t max_frames;       /* SAMPLES, 30; 0 = never freeze */
+    float eps;                 /* EPSILON, 0.001 */
+    float max_dist;            /* MAX_DIST, 5000 */
+    float ao_length;           /* AO_LENGTH, 1 */
+    float hdri_strength;       /* HDRI_STRENGTH, 1 */
+    uint32_t accel;            /* KL_ACCEL_* */
+    uint32_t frames_in_flight; /* frames traced together as one wavefront batch (0 = choose) */
+    uint32_t fused_compaction; /* 1: shade pushes survivors itself; 0: separate compact kernel */
+    uint32_t collect_stats;    /* 1: traversal kernels count nodes/primitives/active lanes (slower) */
+    uint32_t profile_kernels;  /* 1: HIP events around every intersect launch, see kl_get_timing */
+    uint32_t reserved[5];
+} kl_params;
+
+typedef struct kl_counters {
+    uint64_t frames;           /* frames rendered since kl_reset_counters */
+    uint64_t paths;            /* path samples (pixels x frames) */
+    uint64_t rays;             /* rays that entered an intersect kernel */
+    uint64_t nodes;            /* BVH nodes visited          (collect_stats only) */
+    uint64_t sphere_tests, quad_tests, tri_tests; /*          (collect_stats only) */
+    uint64_t lane_steps_active, lane_steps_total; /* traversal-loop lane occupancy (collect_stats only) */
+} kl_counters;
+
+typedef struct kl_timing {
+    double intersect_ms;       /* sum of HIP-event durations of intersect launches (profile_kernels only) */
+    uint64_t intersect_launches;
+    double render_ms;          /* sum of HIP-event durations of whole kl_render_frames calls */
+    uint64_t render_calls;
+} kl_timing;
+
+typedef struct kl_bvh_stats {
+    uint32_t nodes, leaves, max_depth, max_leaf_size;
+    uint32_t spheres, quads, tris;
+    float sah_cost;
+    double build_seconds;
+    uint64_t node_bytes, prim_bytes;
+} kl_bvh_stats;
+
+/* parameters of the seed-deterministic synthetic benchmark scene */
+typedef struct kl_synth_params {
+    uint32_t blobs;            /* tessellated blobs inside the room */
+    uint32_t tris_per_blob;    /* rounded down to 2*k*(k-1) for a k x k lat-long tessellation */
+    uint32_t analytic_spheres; /* extra analytic spheres (mixed sphere/mesh scenes) */
+    uint32_t seed;
+} kl_synth_params;
+
+typedef struct kl_ctx kl_ctx;
+
+/* -- life cycle: GLSL_Renderer::GLSL_Renderer + f_init set-up, GLSL_Renderer.cpp:3-46,164-240 -- */
+KL_API kl_status kl_create(kl_ctx **out, int32_t device, uint32_t width, uint32_t height);
+KL_API kl_status kl_destroy(kl_ctx *ctx);
+/* framebuffer_size_callback, GLSL_Renderer.cpp:67-82: new size, frame counter back to 0 */
+KL_API kl_status kl_resize(kl_ctx *ctx, uint32_t width, uint32_t height);
+/* f_recompile, GLSL_Renderer.cpp:48-65: kernels are compiled ahead of time, so only the reset part remains */
+KL_API kl_status kl_recompile(kl_ctx *ctx);
+
+/* -- uniforms: GLSL_Renderer.cpp:287-298 -- */
+KL_API kl_status kl_set_camera(kl_ctx *ctx, const kl_camera *cam);      /* :293-297; resets like :247-273 */
+KL_API kl_status kl_set_mode(kl_ctx *ctx, uint32_t mode);               /* :290; resets like :140-144 */
+KL_API kl_status kl_default_params(kl_params *p);                       /* RawFrame.glsl:32-40 values */
+KL_API kl_status kl_default_camera(kl_camera *cam);                     /* source/Object/Camera.cpp:3-14 */
+KL_API kl_status kl_set_params(kl_ctx *ctx, const kl_params *p);
+KL_API kl_status kl_get_params(kl_ctx *ctx, kl_params *p);
+/* iFrame = 0, iCameraChange = true: the tail of every input handler, e.g. GLSL_Renderer.cpp:141-143 */
+KL_API kl_status kl_reset(kl_ctx *ctx);
+KL_API kl_status kl_get_frame(kl_ctx *ctx, uint32_t *frame);            /* iFrame, GLSL_Renderer.h:34 */
+
+/* -- textures: Texture::f_init, source/Rendering/Opengl/Texture.cpp:3-16 over Image::f_load,
+ *    source/I-O/File.cpp:13-29: 8-bit, 1/3/4 channels, rows as decoded (no flip), NEAREST, clamp -- */
+KL_API kl_status kl_upload_texture(kl_ctx *ctx, uint32_t which, const uint8_t *pixels,
+                                   uint32_t width, uint32_t height, uint32_t channels);
+
+/* -- scene: replaces the const arrays of RawFrame.glsl:171-192 -- */
+KL_API kl_status kl_upload_scene(kl_ctx *ctx, const kl_sphere *spheres, uint32_t n_spheres,
+                                 const kl_quad *quads, uint32_t n_quads,
+                                 const kl_tri *tris, uint32_t n_tris,
+                                 const kl_material *materials, uint32_t n_materials);
+KL_API kl_status kl_load_builtin_scene(kl_ctx *ctx);                    /* RawFrame.glsl:171-192 */
+KL_API kl_status kl_get_bvh_stats(kl_ctx *ctx, kl_bvh_stats *out);
+/* synthetic benchmark scene (no reference counterpart): sizes first, then fill caller-owned arrays */
+KL_API kl_status kl_synth_scene_counts(const kl_synth_params *sp, uint32_t *n_spheres, uint32_t *n_quads,
+                                       uint32_t *n_tris, uint32_t *n_materials);
+KL_API kl_status kl_synth_scene_fill(const kl_synth_params *sp, kl_sphere *spheres, kl_quad *quads,
+                                     kl_tri *tris, kl_material *materials);
+
+/* -- the frame loop body: passes 1 and 2 of GLSL_Renderer.cpp:283-328 plus iFrame++ (:347), n times.
+ *    first_frame = KL_CONTINUE continues from the context's frame counter -- */
+KL_API kl_status kl_render_frames(kl_ctx *ctx, uint32_t n, uint32_t first_frame);
+KL_API kl_status kl_synchronize(kl_ctx *ctx);
+
+/* -- results: what raw_frame_tex / accumulation_tex hold (GLSL_Renderer.cpp:223-234), float RGBA,
+ *    row 0 = bottom row (gl_FragCoord.y = 0.5); and pass 3, PostProcess.glsl:34-39 -- */
+KL_API kl_status kl_read_raw(kl_ctx *ctx, float *rgba, size_t bytes);
+KL_API kl_status kl_read_accum(kl_ctx *ctx, float *rgba, size_t bytes);
+KL_API kl_status kl_resolve(kl_ctx *ctx, uint32_t tonemap, uint8_t *rgba8, size_t bytes);
+
+/* -- measurement (no reference counterpart; the reference only shows 1/frame_time in the
+ *    window title, GLSL_Renderer.cpp:350-355) -- */
+KL_API kl_status kl_get_counters(kl_ctx *ctx, kl_counters *out);
+KL_API kl_status kl_reset_counters(kl_ctx *ctx);
+KL_API kl_status kl_get_timing(kl_ctx *ctx, kl_timing *out);
+/* closest hit for caller-supplied rays through the same intersect kernel the renderer uses:
+ * o, d are n x 3 floats; t (n), prim (n, declaration-order id or 0xFFFFFFFF), uv (n x 2) are outputs */
+KL_API kl_status kl_trace_rays(kl_ctx *ctx, const float *o, const float *d, uint32_t n,
+                               float *t, uint32_t *prim, float *uv);
+
+/* -- partitioning over GPUs (no reference counterpart). Image tiles: this context renders the
+ *    row bands b with b % world == rank, band_rows rows each; its buffers then hold only those
+ *    rows, top band first. Sample ranges: use KL_ACCUM_SUM and disjoint first_frame ranges. -- */
+KL_API kl_status kl_set_shard(kl_ctx *ctx, uint32_t rank, uint32_t world, uint32_t band_rows);
+KL_API kl_status kl_get_local_rows(kl_ctx *ctx, uint32_t *rows);
+KL_API kl_status kl_set_accum_mode(kl_ctx *ctx, uint32_t mode);
+/* device-to-device copies of the accumulation buffer for collectives run by the caller
+ * (e.g. torch.distributed over RCCL); dst/src are device pointers on the context's device */
+KL_API kl_status kl_copy_accum_to_device(kl_ctx *ctx, void *dst_device, size_t bytes);
+KL_API kl_status kl_copy_accum_from_device(kl_ctx *ctx, const void *src_device, size_t bytes);
+
+KL_API const char *kl_status_string(kl_status s);
+KL_API const char *kl_last_error(kl_ctx *ctx);
+KL_API uint32_t kl_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KL_RENDER_H */

@@ -1,0 +1,630 @@
+// C-ABI implementation (include/Math/kl_render.h): context, uploads, the frame
+// loop that sequences the wavefront kernels on one HIP stream, read-back.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "Math/kl_render.h"
+#include "kl_bvh.hpp"
+#include "kl_kernels.hpp"
+#include "kl_math.hpp"
+#include "kl_scene.hpp"
+#include "kl_types.hpp"
+
+using namespace kl;
+
+namespace {
+constexpr uint32_t KL_MAX_BOUNCES = 4096;
+constexpr uint32_t KL_MAX_DIM = 32768;
+constexpr uint32_t KL_MAX_FRAMES_IN_FLIGHT = 64;
+constexpr uint32_t KL_BRUTE_AUTO_LIMIT = 64;      // KL_ACCEL_AUTO uses the flat loop up to this many primitives
+constexpr size_t KL_MAX_PENDING_EVENTS = 8192;
+
+struct EventPair { hipEvent_t a, b; int kind; };   // kind 0 = intersect launch, 1 = whole render call
+
+template <typename T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    hipError_t alloc(size_t count) {
+        if (count == n && p) return hipSuccess;
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count; else p = nullptr;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+}  // namespace
+
+struct kl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    LaunchCfg lc{256, 5};
+    uint32_t width = 0, height = 0;
+    uint32_t rank = 0, world = 1, band_rows = 1, local_rows = 0, npl = 0;
+    kl_camera cam;
+    uint32_t mode = KL_MODE_PT;
+    kl_params params;
+    uint32_t accum_mode = KL_ACCUM_MEAN;
+    uint32_t frame = 0;
+    bool camera_change = true;
+    // scene
+    bool have_scene = false;
+    uint32_t n_prims = 0;
+    SceneDev sc;
+    kl_bvh_stats bvh_stats;
+    DevBuf<float4> d_nodes, d_sph, d_quad, d_tri, d_tri_shade, d_mats;
+    DevBuf<uint32_t> d_sph_id, d_quad_id, d_sph_mat, d_quad_mat;
+    DevBuf<uchar4> d_tex[2];
+    // wavefront state
+    uint32_t slots = 0;               // frames in flight the buffers are sized for
+    DevBuf<float4> d_od[2], d_tp[2], d_hits, d_raw, d_acc, d_last_raw;
+    DevBuf<float2> d_d2[2];
+    DevBuf<uint32_t> d_qctl;          // count[0..B], head[0..B]
+    DevBuf<Counters> d_counters;
+    DevBuf<uchar4> d_resolve;
+    // bookkeeping
+    uint64_t frames_total = 0, paths_total = 0;
+    std::vector<hipEvent_t> free_events;
+    std::vector<EventPair> pending;
+    kl_timing timing{};
+    std::string err;
+};
+
+namespace {
+
+kl_status fail(kl_ctx *c, kl_status s, const std::string &msg) { if (c) c->err = msg; return s; }
+
+#define KL_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? KL_E_NOMEM : KL_E_DEVICE,                 \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+void compute_local(kl_ctx *c) {
+    uint32_t rows = 0;
+    uint32_t bands = (c->height + c->band_rows - 1) / c->band_rows;
+    for (uint32_t b = c->rank; b < bands; b += c->world) {
+        uint32_t y0 = b * c->band_rows, y1 = std::min(c->height, y0 + c->band_rows);
+        rows += y1 - y0;
+    }
+    c->local_rows = rows;
+    c->npl = rows * c->width;
+}
+
+uint32_t choose_slots(const kl_ctx *c) {
+    uint32_t f = c->params.frames_in_flight;
+    if (f == 0) {
+        // about eight million paths per batch keeps every CU busy through the late bounces
+        uint64_t npl = std::max<uint32_t>(c->npl, 1);
+        f = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, (8u << 20) / npl));
+    }
+    return std::min(f, KL_MAX_FRAMES_IN_FLIGHT);
+}
+
+kl_status ensure_buffers(kl_ctx *c) {
+    KL_HIP(c, hipSetDevice(c->device));
+    const uint32_t slots = choose_slots(c);
+    const size_t cap = (size_t)slots * c->npl;
+    if (cap >= (1ull << 32)) return fail(c, KL_E_LIMIT, "frames_in_flight x pixels exceeds 2^32 paths");
+    c->slots = slots;
+    for (int k = 0; k < 2; k++) {
+        KL_HIP(c, c->d_od[k].alloc(cap)); KL_HIP(c, c->d_d2[k].alloc(cap)); KL_HIP(c, c->d_tp[k].alloc(cap));
+    }
+    KL_HIP(c, c->d_hits.alloc(cap));
+    KL_HIP(c, c->d_raw.alloc(cap));
+    bool fresh = c->d_acc.n != c->npl;
+    KL_HIP(c, c->d_acc.alloc(c->npl));
+    KL_HIP(c, c->d_last_raw.alloc(c->npl));
+    if (fresh && c->npl) {
+        KL_HIP(c, hipMemsetAsync(c->d_acc.p, 0, c->npl * sizeof(float4), c->stream));
+        KL_HIP(c, hipMemsetAsync(c->d_last_raw.p, 0, c->npl * sizeof(float4), c->stream));
+    }
+    KL_HIP(c, c->d_qctl.alloc(2 * ((size_t)c->params.max_bounces + 2)));
+    if (!c->d_counters.p) {
+        KL_HIP(c, c->d_counters.alloc(1));
+        KL_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream));
+    }
+    return KL_OK;
+}
+
+hipEvent_t get_event(kl_ctx *c) {
+    if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+void drain_events(kl_ctx *c) {
+    if (c->pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (const EventPair &p : c->pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            if (p.kind == 0) { c->timing.intersect_ms += ms; c->timing.intersect_launches++; }
+            else { c->timing.render_ms += ms; c->timing.render_calls++; }
+        }
+        c->free_events.push_back(p.a); c->free_events.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+void soft_reset(kl_ctx *c) { c->frame = 0; c->camera_change = true; }
+
+FrameDev make_frame(const kl_ctx *c, uint32_t first_frame, uint32_t nslots) {
+    FrameDev f; std::memset(&f, 0, sizeof f);
+    // projection frame of RawFrame.glsl:418-420, evaluated once on the host with the same fp32 operations
+    v3 pos = V(c->cam.pos[0], c->cam.pos[1], c->cam.pos[2]);
+    v3 front = V(c->cam.front[0], c->cam.front[1], c->cam.front[2]);
+    v3 up = V(c->cam.up[0], c->cam.up[1], c->cam.up[2]);
+    v3 pc = pos + front * c->cam.focal;
+    v3 pu = normalize(cross(front, up)) * c->cam.sensor;
+    v3 pv = normalize(cross(pu, front)) * (c->cam.sensor / 1.0f);
+    f.pos[0] = pos.x; f.pos[1] = pos.y; f.pos[2] = pos.z;
+    f.pc[0] = pc.x; f.pc[1] = pc.y; f.pc[2] = pc.z;
+    f.pu[0] = pu.x; f.pu[1] = pu.y; f.pu[2] = pu.z;
+    f.pv[0] = pv.x; f.pv[1] = pv.y; f.pv[2] = pv.z;
+    f.width = c->width; f.height = c->height; f.npl = c->npl;
+    f.rank = c->rank; f.world = c->world; f.band_rows = c->band_rows;
+    f.mode = c->mode; f.first_frame = first_frame; f.nslots = nslots;
+    f.max_bounces = c->params.max_bounces; f.max_frames = c->params.max_frames;
+    f.eps = c->params.eps; f.max_dist = c->params.max_dist;
+    f.ao_length = c->params.ao_length; f.hdri_strength = c->params.hdri_strength;
+    return f;
+}
+
+bool use_bvh(const kl_ctx *c) {
+    if (c->sc.root == NODE_DONE) return false;
+    if (c->params.accel == KL_ACCEL_BVH) return true;
+    if (c->params.accel == KL_ACCEL_BRUTE) return false;
+    return c->n_prims > KL_BRUTE_AUTO_LIMIT;
+}
+
+kl_status timed_intersect(kl_ctx *c, const FrameDev &f, RayQueue q, uint32_t *count, uint32_t *head, uint32_t max_rays) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (c->params.profile_kernels) {
+        if (c->pending.size() >= KL_MAX_PENDING_EVENTS) drain_events(c);
+        a = get_event(c); b = get_event(c);
+        if (a && b) KL_HIP(c, hipEventRecord(a, c->stream));
+    }
+    launch_intersect(c->stream, c->lc, c->sc, f, q, c->d_hits.p, count, head, c->d_counters.p, use_bvh(c),
+                     c->params.collect_stats != 0, max_rays);
+    if (a && b) { KL_HIP(c, hipEventRecord(b, c->stream)); c->pending.push_back({a, b, 0}); }
+    return KL_OK;
+}
+
+// one wavefront batch: frames [first, first+nslots) traced together, then accumulated in order
+kl_status render_batch(kl_ctx *c, uint32_t first, uint32_t nslots, bool camera_change) {
+    FrameDev f = make_frame(c, first, nslots);
+    const uint32_t B = c->params.max_bounces;
+    uint32_t *count = c->d_qctl.p, *head = c->d_qctl.p + (B + 2);
+    const uint32_t max_rays = nslots * c->npl;
+    RayQueue q[2] = { {c->d_od[0].p, c->d_d2[0].p, c->d_tp[0].p}, {c->d_od[1].p, c->d_d2[1].p, c->d_tp[1].p} };
+    const bool fused = c->params.fused_compaction != 0;
+    KL_HIP(c, hipMemsetAsync(c->d_qctl.p, 0, c->d_qctl.n * sizeof(uint32_t), c->stream));
+    launch_generate(c->stream, c->lc, f, q[0], &count[0]);
+    const uint32_t levels = c->mode == KL_MODE_PT ? B : (c->mode == KL_MODE_AO ? 2u : 1u);
+    for (uint32_t b = 0; b < levels; b++) {
+        RayQueue qi = q[b & 1u], qo = q[(b + 1u) & 1u];
+        kl_status s = timed_intersect(c, f, qi, &count[b], &head[b], max_rays);
+        if (s != KL_OK) return s;
+        launch_shade(c->stream, c->lc, c->sc, f, qi, c->d_hits.p, &count[b], qo, &count[b + 1], c->d_raw.p, b, fused, max_rays);
+        if (!fused && b + 1 < levels) launch_compact(c->stream, c->lc, qi, &count[b], qo, &count[b + 1], max_rays);
+    }
+    launch_accumulate(c->stream, c->lc, f, c->d_raw.p, c->d_acc.p, c->d_last_raw.p, camera_change, c->accum_mode);
+    KL_HIP(c, hipGetLastError());
+    return KL_OK;
+}
+
+template <typename T> kl_status upload(kl_ctx *c, DevBuf<T> &buf, const void *src, size_t count) {
+    KL_HIP(c, buf.alloc(std::max<size_t>(count, 1)));
+    if (count) KL_HIP(c, hipMemcpyAsync(buf.p, src, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return KL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t kl_abi_version(void) { return 1; }
+
+const char *kl_status_string(kl_status s) {
+    switch (s) {
+        case KL_OK: return "ok";
+        case KL_E_INVALID: return "invalid argument";
+        case KL_E_DEVICE: return "HIP runtime error";
+        case KL_E_NOMEM: return "out of memory";
+        case KL_E_STATE: return "invalid state";
+        case KL_E_LIMIT: return "size beyond a documented maximum";
+        default: return "unknown status";
+    }
+}
+const char *kl_last_error(kl_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+kl_status kl_default_params(kl_params *p) {
+    if (!p) return KL_E_INVALID;
+    std::memset(p, 0, sizeof *p);
+    p->max_bounces = 32; p->max_frames = 30; p->eps = 0.001f; p->max_dist = 5000.0f;
+    p->ao_length = 1.0f; p->hdri_strength = 1.0f; p->accel = KL_ACCEL_AUTO;
+    p->frames_in_flight = 0; p->fused_compaction = 1; p->collect_stats = 0; p->profile_kernels = 0;
+    return KL_OK;
+}
+kl_status kl_default_camera(kl_camera *cam) {
+    if (!cam) return KL_E_INVALID;
+    const kl_camera d = { {0, 1, 5}, {0, 0, -1}, {0, 1, 0}, 0.05f, 0.036f };
+    *cam = d;
+    return KL_OK;
+}
+
+kl_status kl_create(kl_ctx **out, int32_t device, uint32_t width, uint32_t height) {
+    if (!out) return KL_E_INVALID;
+    *out = nullptr;
+    if (width == 0 || height == 0 || width > KL_MAX_DIM || height > KL_MAX_DIM) return KL_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return KL_E_DEVICE;
+    kl_ctx *c = new (std::nothrow) kl_ctx();
+    if (!c) return KL_E_NOMEM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c; return KL_E_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->lc.cus = (uint32_t)prop.multiProcessorCount;
+    c->lc.isect_blocks_per_cu = 5;   // 4 waves x 8 KiB of traversal stack each -> five workgroups fill a CU's 160 KiB LDS
+    c->width = width; c->height = height;
+    kl_default_camera(&c->cam);
+    kl_default_params(&c->params);
+    std::memset(&c->sc, 0, sizeof c->sc);
+    c->sc.root = NODE_DONE;
+    std::memset(&c->bvh_stats, 0, sizeof c->bvh_stats);
+    compute_local(c);
+    // 1x1 white textures until the caller uploads real ones
+    const uint8_t white[4] = {255, 255, 255, 255};
+    *out = c;
+    kl_status s = kl_upload_texture(c, KL_TEX_HDRI, white, 1, 1, 4);
+    if (s == KL_OK) s = kl_upload_texture(c, KL_TEX_ALBEDO, white, 1, 1, 4);
+    if (s != KL_OK) { kl_destroy(c); *out = nullptr; }
+    return s;
+}
+
+kl_status kl_destroy(kl_ctx *c) {
+    if (!c) return KL_E_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (const EventPair &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
+    c->d_nodes.release(); c->d_sph.release(); c->d_quad.release(); c->d_tri.release(); c->d_tri_shade.release();
+    c->d_mats.release(); c->d_sph_id.release(); c->d_quad_id.release(); c->d_sph_mat.release(); c->d_quad_mat.release();
+    for (int k = 0; k < 2; k++) { c->d_tex[k].release(); c->d_od[k].release(); c->d_d2[k].release(); c->d_tp[k].release(); }
+    c->d_hits.release(); c->d_raw.release(); c->d_acc.release(); c->d_last_raw.release();
+    c->d_qctl.release(); c->d_counters.release(); c->d_resolve.release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return KL_OK;
+}
+
+kl_status kl_resize(kl_ctx *c, uint32_t width, uint32_t height) {
+    if (!c || width == 0 || height == 0 || width > KL_MAX_DIM || height > KL_MAX_DIM) return fail(c, KL_E_INVALID, "bad size");
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    c->width = width; c->height = height;
+    compute_local(c);
+    c->d_acc.release();          // new attachments, as FBT::f_resize does
+    c->frame = 0;                // :72 resets iFrame but not iCameraChange
+    return KL_OK;
+}
+kl_status kl_recompile(kl_ctx *c) { if (!c) return KL_E_INVALID; soft_reset(c); return KL_OK; }
+kl_status kl_reset(kl_ctx *c) {
+    if (!c) return KL_E_INVALID;
+    soft_reset(c);
+    // a fresh accumulation: frame 0 then yields exactly the raw frame even if a stale texel was non-finite
+    if (c->d_acc.p) KL_HIP(c, hipMemsetAsync(c->d_acc.p, 0, c->d_acc.n * sizeof(float4), c->stream));
+    return KL_OK;
+}
+kl_status kl_get_frame(kl_ctx *c, uint32_t *frame) { if (!c || !frame) return KL_E_INVALID; *frame = c->frame; return KL_OK; }
+
+kl_status kl_set_camera(kl_ctx *c, const kl_camera *cam) {
+    if (!c || !cam) return fail(c, KL_E_INVALID, "null camera");
+    c->cam = *cam;
+    return kl_reset(c);
+}
+kl_status kl_set_mode(kl_ctx *c, uint32_t mode) {
+    if (!c || mode > KL_MODE_Z) return fail(c, KL_E_INVALID, "mode must be 0 (AO), 1 (path traced) or 2 (ZDepth)");
+    c->mode = mode;
+    return kl_reset(c);
+}
+kl_status kl_set_params(kl_ctx *c, const kl_params *p) {
+    if (!c || !p) return fail(c, KL_E_INVALID, "null params");
+    if (p->max_bounces == 0 || p->max_bounces > KL_MAX_BOUNCES) return fail(c, KL_E_LIMIT, "max_bounces must be 1..4096");
+    if (p->frames_in_flight > KL_MAX_FRAMES_IN_FLIGHT) return fail(c, KL_E_LIMIT, "frames_in_flight must be <= 64");
+    if (p->accel > KL_ACCEL_BVH) return fail(c, KL_E_INVALID, "bad accel");
+    if (!(p->max_dist > 0.0f) || !(p->eps >= 0.0f)) return fail(c, KL_E_INVALID, "bad eps/max_dist");
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    c->params = *p;
+    return KL_OK;
+}
+kl_status kl_get_params(kl_ctx *c, kl_params *p) { if (!c || !p) return KL_E_INVALID; *p = c->params; return KL_OK; }
+
+kl_status kl_upload_texture(kl_ctx *c, uint32_t which, const uint8_t *px, uint32_t w, uint32_t h, uint32_t ch) {
+    if (!c || which > KL_TEX_ALBEDO || !px || !w || !h || w > KL_MAX_DIM || h > KL_MAX_DIM || (ch != 1 && ch != 3 && ch != 4))
+        return fail(c, KL_E_INVALID, "texture must be 8-bit with 1, 3 or 4 channels");
+    KL_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)w * h;
+    std::vector<uchar4> tmp(n);
+    for (size_t i = 0; i < n; i++) {
+        if (ch == 4) tmp[i] = make_uchar4(px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3]);
+        else if (ch == 3) tmp[i] = make_uchar4(px[3 * i], px[3 * i + 1], px[3 * i + 2], 255);
+        else tmp[i] = make_uchar4(px[i], 0, 0, 255);       // GL_RED upload: g = b = 0 (Texture.cpp:13-14)
+    }
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    KL_HIP(c, c->d_tex[which].alloc(n));
+    KL_HIP(c, hipMemcpy(c->d_tex[which].p, tmp.data(), n * sizeof(uchar4), hipMemcpyHostToDevice));
+    c->sc.tex[which] = c->d_tex[which].p; c->sc.tex_w[which] = w; c->sc.tex_h[which] = h;
+    return KL_OK;
+}
+
+kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq,
+                          const kl_tri *t, uint32_t nt, const kl_material *m, uint32_t nm) {
+    if (!c || (ns && !s) || (nq && !q) || (nt && !t) || !m || nm == 0) return fail(c, KL_E_INVALID, "null scene array");
+    if (ns >= MAX_PRIMS_PER_TYPE || nq >= MAX_PRIMS_PER_TYPE || nt >= MAX_PRIMS_PER_TYPE)
+        return fail(c, KL_E_LIMIT, "at most 2^26 primitives per type");
+    for (uint32_t i = 0; i < ns; i++) if (s[i].material >= nm) return fail(c, KL_E_INVALID, "sphere material index out of range");
+    for (uint32_t i = 0; i < nq; i++) if (q[i].material >= nm) return fail(c, KL_E_INVALID, "quad material index out of range");
+    for (uint32_t i = 0; i < nt; i++) if (t[i].material >= nm) return fail(c, KL_E_INVALID, "triangle material index out of range");
+    KL_HIP(c, hipSetDevice(c->device));
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    HostBVH bvh;
+    unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    build_bvh(s, ns, q, nq, t, nt, bvh, threads);
+    // leaf-ordered geometry and shading arrays
+    std::vector<float4> sph(ns), quad((size_t)nq * 3), tri((size_t)nt * 3), tsh((size_t)nt * 2), mats((size_t)nm * 2);
+    std::vector<uint32_t> sph_id(ns), quad_id(nq), sph_mat(ns), quad_mat(nq);
+    for (uint32_t k = 0; k < ns; k++) {
+        const kl_sphere &x = s[bvh.sph_order[k]];
+        sph[k] = make_float4(x.center[0], x.center[1], x.center[2], x.radius);
+        sph_id[k] = bvh.sph_order[k]; sph_mat[k] = x.material;
+    }
+    for (uint32_t k = 0; k < nq; k++) {
+        const kl_quad &x = q[bvh.quad_order[k]];
+        quad[3 * (size_t)k] = make_float4(x.v0[0], x.v0[1], x.v0[2], x.v1[0]);
+        quad[3 * (size_t)k + 1] = make_float4(x.v1[1], x.v1[2], x.v2[0], x.v2[1]);
+        quad[3 * (size_t)k + 2] = make_float4(x.v2[2], x.v3[0], x.v3[1], x.v3[2]);
+        quad_id[k] = ns + bvh.quad_order[k]; quad_mat[k] = x.material;
+    }
+    for (uint32_t k = 0; k < nt; k++) {
+        const kl_tri &x = t[bvh.tri_order[k]];
+        v3 v0 = V(x.v0[0], x.v0[1], x.v0[2]);
+        v3 e1 = V(x.v1[0], x.v1[1], x.v1[2]) - v0, e2 = V(x.v2[0], x.v2[1], x.v2[2]) - v0;
+        uint32_t id = ns + nq + bvh.tri_order[k];
+        float idf, matf; std::memcpy(&idf, &id, 4); std::memcpy(&matf, &x.material, 4);
+        tri[3 * (size_t)k] = make_float4(v0.x, v0.y, v0.z, e1.x);
+        tri[3 * (size_t)k + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+        tri[3 * (size_t)k + 2] = make_float4(e2.z, idf, 0.0f, 0.0f);
+        tsh[2 * (size_t)k] = make_float4(x.uv0[0], x.uv0[1], x.uv1[0], x.uv1[1]);
+        tsh[2 * (size_t)k + 1] = make_float4(x.uv2[0], x.uv2[1], matf, 0.0f);
+    }
+    for (uint32_t k = 0; k < nm; k++) {
+        float tf; std::memcpy(&tf, &m[k].type, 4);
+        mats[2 * (size_t)k] = make_float4(tf, m[k].color[0], m[k].color[1], m[k].color[2]);
+        mats[2 * (size_t)k + 1] = make_float4(m[k].emissive, m[k].roughness, m[k].ior, 0.0f);
+    }
+    kl_status st;
+    if ((st = upload(c, c->d_nodes, bvh.nodes.data(), bvh.nodes.size() / 4)) != KL_OK) return st;
+    if ((st = upload(c, c->d_sph, sph.data(), sph.size())) != KL_OK) return st;
+    if ((st = upload(c, c->d_quad, quad.data(), quad.size())) != KL_OK) return st;
+    if ((st = upload(c, c->d_tri, tri.data(), tri.size())) != KL_OK) return st;
+    if ((st = upload(c, c->d_tri_shade, tsh.data(), tsh.size())) != KL_OK) return st;
+    if ((st = upload(c, c->d_mats, mats.data(), mats.size())) != KL_OK) return st;
+    if ((st = upload(c, c->d_sph_id, sph_id.data(), sph_id.size())) != KL_OK) return st;
+    if ((st = upload(c, c->d_quad_id, quad_id.data(), quad_id.size())) != KL_OK) return st;
+    if ((st = upload(c, c->d_sph_mat, sph_mat.data(), sph_mat.size())) != KL_OK) return st;
+    if ((st = upload(c, c->d_quad_mat, quad_mat.data(), quad_mat.size())) != KL_OK) return st;
+    KL_HIP(c, hipStreamSynchronize(c->stream));     // the host vectors go out of scope below
+    c->sc.nodes = c->d_nodes.p; c->sc.root = bvh.root; c->sc.n_nodes = bvh.stats.nodes;
+    c->sc.sph = c->d_sph.p; c->sc.quad = c->d_quad.p; c->sc.tri = c->d_tri.p;
+    c->sc.sph_id = c->d_sph_id.p; c->sc.quad_id = c->d_quad_id.p;
+    c->sc.sph_mat = c->d_sph_mat.p; c->sc.quad_mat = c->d_quad_mat.p;
+    c->sc.tri_shade = c->d_tri_shade.p; c->sc.mats = c->d_mats.p;
+    c->sc.ns = ns; c->sc.nq = nq; c->sc.nt = nt; c->sc.nm = nm;
+    c->n_prims = ns + nq + nt;
+    c->bvh_stats = bvh.stats;
+    c->bvh_stats.prim_bytes = (uint64_t)ns * 16 + (uint64_t)nq * 48 + (uint64_t)nt * 48;
+    c->have_scene = true;
+    return kl_reset(c);
+}
+
+kl_status kl_load_builtin_scene(kl_ctx *c) {
+    if (!c) return KL_E_INVALID;
+    std::vector<kl_sphere> s; std::vector<kl_quad> q; std::vector<kl_material> m;
+    builtin_scene(s, q, m);
+    return kl_upload_scene(c, s.data(), (uint32_t)s.size(), q.data(), (uint32_t)q.size(), nullptr, 0, m.data(), (uint32_t)m.size());
+}
+kl_status kl_get_bvh_stats(kl_ctx *c, kl_bvh_stats *out) {
+    if (!c || !out) return KL_E_INVALID;
+    if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");
+    *out = c->bvh_stats;
+    return KL_OK;
+}
+kl_status kl_synth_scene_counts(const kl_synth_params *sp, uint32_t *ns, uint32_t *nq, uint32_t *nt, uint32_t *nm) {
+    if (!sp || !ns || !nq || !nt || !nm || sp->tris_per_blob < 12) return KL_E_INVALID;
+    if ((uint64_t)sp->blobs * sp->tris_per_blob >= MAX_PRIMS_PER_TYPE || sp->analytic_spheres >= MAX_PRIMS_PER_TYPE) return KL_E_LIMIT;
+    synth_counts(*sp, *ns, *nq, *nt, *nm);
+    return KL_OK;
+}
+kl_status kl_synth_scene_fill(const kl_synth_params *sp, kl_sphere *s, kl_quad *q, kl_tri *t, kl_material *m) {
+    uint32_t ns, nq, nt, nm;
+    kl_status st = kl_synth_scene_counts(sp, &ns, &nq, &nt, &nm);
+    if (st != KL_OK) return st;
+    if ((ns && !s) || !q || (nt && !t) || !m) return KL_E_INVALID;
+    synth_fill(*sp, s, q, t, m);
+    return KL_OK;
+}
+
+kl_status kl_render_frames(kl_ctx *c, uint32_t n, uint32_t first_frame) {
+    if (!c) return KL_E_INVALID;
+    if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");
+    if (c->npl == 0 || n == 0) return KL_OK;
+    kl_status s = ensure_buffers(c);
+    if (s != KL_OK) return s;
+    uint32_t frame = first_frame == KL_CONTINUE ? c->frame : first_frame;
+    if ((uint64_t)frame + n > 0xFFFFFFFEull) return fail(c, KL_E_LIMIT, "frame index overflow");
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (c->pending.size() >= KL_MAX_PENDING_EVENTS) drain_events(c);
+    ea = get_event(c); eb = get_event(c);
+    if (ea && eb) KL_HIP(c, hipEventRecord(ea, c->stream));
+    uint32_t left = n;
+    while (left) {
+        const uint32_t mf = c->params.max_frames;
+        uint32_t k;
+        if (mf && frame >= mf) {
+            // past SAMPLES the raw frame is the accumulation texel (RawFrame.glsl:461-463): nothing to trace
+            k = std::min(left, 1024u);
+            FrameDev f = make_frame(c, frame, k);
+            launch_accumulate(c->stream, c->lc, f, c->d_raw.p, c->d_acc.p, c->d_last_raw.p, false, c->accum_mode);
+        } else {
+            k = std::min(left, c->slots);
+            if (mf) k = std::min(k, mf - frame);
+            if ((s = render_batch(c, frame, k, c->camera_change)) != KL_OK) return s;
+            c->paths_total += (uint64_t)k * c->npl;
+        }
+        c->camera_change = false;       // GLSL_Renderer.cpp:348
+        frame += k; left -= k;
+        c->frames_total += k;
+    }
+    c->frame = frame;                   // iFrame++ per frame, GLSL_Renderer.cpp:347
+    if (ea && eb) { KL_HIP(c, hipEventRecord(eb, c->stream)); c->pending.push_back({ea, eb, 1}); }
+    return KL_OK;
+}
+
+kl_status kl_synchronize(kl_ctx *c) {
+    if (!c) return KL_E_INVALID;
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    return KL_OK;
+}
+
+static kl_status read_buf(kl_ctx *c, const DevBuf<float4> &b, float *rgba, size_t bytes) {
+    if (!c || !rgba) return fail(c, KL_E_INVALID, "null output");
+    if (!b.p || b.n != c->npl) return fail(c, KL_E_STATE, "nothing rendered yet");
+    if (bytes != (size_t)c->npl * 16) return fail(c, KL_E_INVALID, "output must be local_rows x width x 16 bytes");
+    KL_HIP(c, hipMemcpyAsync(rgba, b.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    return KL_OK;
+}
+kl_status kl_read_raw(kl_ctx *c, float *rgba, size_t bytes) { return c ? read_buf(c, c->d_last_raw, rgba, bytes) : KL_E_INVALID; }
+kl_status kl_read_accum(kl_ctx *c, float *rgba, size_t bytes) { return c ? read_buf(c, c->d_acc, rgba, bytes) : KL_E_INVALID; }
+
+kl_status kl_resolve(kl_ctx *c, uint32_t tonemap, uint8_t *rgba8, size_t bytes) {
+    if (!c || !rgba8 || tonemap > KL_TONEMAP_ACES) return fail(c, KL_E_INVALID, "bad resolve arguments");
+    if (!c->d_acc.p || c->d_acc.n != c->npl) return fail(c, KL_E_STATE, "nothing rendered yet");
+    if (bytes != (size_t)c->npl * 4) return fail(c, KL_E_INVALID, "output must be local_rows x width x 4 bytes");
+    KL_HIP(c, c->d_resolve.alloc(c->npl));
+    launch_resolve(c->stream, c->lc, c->d_acc.p, c->d_resolve.p, c->npl, tonemap);
+    KL_HIP(c, hipMemcpyAsync(rgba8, c->d_resolve.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    return KL_OK;
+}
+
+kl_status kl_get_counters(kl_ctx *c, kl_counters *out) {
+    if (!c || !out) return KL_E_INVALID;
+    std::memset(out, 0, sizeof *out);
+    out->frames = c->frames_total; out->paths = c->paths_total;
+    if (c->d_counters.p) {
+        Counters h;
+        KL_HIP(c, hipMemcpyAsync(&h, c->d_counters.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        KL_HIP(c, hipStreamSynchronize(c->stream));
+        out->rays = h.rays; out->nodes = h.nodes; out->sphere_tests = h.sphere_tests; out->quad_tests = h.quad_tests;
+        out->tri_tests = h.tri_tests; out->lane_steps_active = h.lane_active; out->lane_steps_total = h.lane_total;
+    }
+    return KL_OK;
+}
+kl_status kl_reset_counters(kl_ctx *c) {
+    if (!c) return KL_E_INVALID;
+    c->frames_total = 0; c->paths_total = 0;
+    drain_events(c);
+    std::memset(&c->timing, 0, sizeof c->timing);
+    if (c->d_counters.p) KL_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream));
+    return KL_OK;
+}
+kl_status kl_get_timing(kl_ctx *c, kl_timing *out) {
+    if (!c || !out) return KL_E_INVALID;
+    drain_events(c);
+    *out = c->timing;
+    return KL_OK;
+}
+
+kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, float *t, uint32_t *prim, float *uv) {
+    if (!c || !o || !d || !t || !prim || !uv) return fail(c, KL_E_INVALID, "null ray arrays");
+    if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");
+    if (n == 0) return KL_OK;
+    if (n > (1u << 28)) return fail(c, KL_E_LIMIT, "at most 2^28 rays per call");
+    KL_HIP(c, hipSetDevice(c->device));
+    std::vector<float4> od(n); std::vector<float2> d2(n);
+    for (uint32_t i = 0; i < n; i++) {
+        od[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i]);
+        d2[i] = make_float2(d[3 * i + 1], d[3 * i + 2]);
+    }
+    DevBuf<float4> b_od, b_hits; DevBuf<float2> b_d2, b_uv; DevBuf<float> b_t; DevBuf<uint32_t> b_prim, b_ctl;
+    struct Cleanup { DevBuf<float4> &a, &b; DevBuf<float2> &c, &d; DevBuf<float> &e; DevBuf<uint32_t> &f, &g;
+                     ~Cleanup() { a.release(); b.release(); c.release(); d.release(); e.release(); f.release(); g.release(); } }
+        cleanup{b_od, b_hits, b_d2, b_uv, b_t, b_prim, b_ctl};
+    KL_HIP(c, b_od.alloc(n)); KL_HIP(c, b_hits.alloc(n)); KL_HIP(c, b_d2.alloc(n)); KL_HIP(c, b_uv.alloc(n));
+    KL_HIP(c, b_t.alloc(n)); KL_HIP(c, b_prim.alloc(n)); KL_HIP(c, b_ctl.alloc(2));
+    if (!c->d_counters.p) { KL_HIP(c, c->d_counters.alloc(1)); KL_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream)); }
+    const uint32_t ctl[2] = { n, 0 };
+    KL_HIP(c, hipMemcpyAsync(b_od.p, od.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    KL_HIP(c, hipMemcpyAsync(b_d2.p, d2.data(), n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    KL_HIP(c, hipMemcpyAsync(b_ctl.p, ctl, sizeof ctl, hipMemcpyHostToDevice, c->stream));
+    FrameDev f = make_frame(c, 0, 1);
+    RayQueue q = { b_od.p, b_d2.p, nullptr };
+    launch_intersect(c->stream, c->lc, c->sc, f, q, b_hits.p, &b_ctl.p[0], &b_ctl.p[1], c->d_counters.p, use_bvh(c),
+                     c->params.collect_stats != 0, n);
+    launch_unpack_hits(c->stream, c->sc, b_hits.p, n, b_t.p, b_prim.p, b_uv.p);
+    KL_HIP(c, hipMemcpyAsync(t, b_t.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    KL_HIP(c, hipMemcpyAsync(prim, b_prim.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    KL_HIP(c, hipMemcpyAsync(uv, b_uv.p, n * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    KL_HIP(c, hipGetLastError());
+    return KL_OK;
+}
+
+kl_status kl_set_shard(kl_ctx *c, uint32_t rank, uint32_t world, uint32_t band_rows) {
+    if (!c || world == 0 || rank >= world || band_rows == 0) return fail(c, KL_E_INVALID, "need rank < world and band_rows >= 1");
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    c->rank = rank; c->world = world; c->band_rows = band_rows;
+    compute_local(c);
+    c->d_acc.release();
+    soft_reset(c);
+    return KL_OK;
+}
+kl_status kl_get_local_rows(kl_ctx *c, uint32_t *rows) { if (!c || !rows) return KL_E_INVALID; *rows = c->local_rows; return KL_OK; }
+kl_status kl_set_accum_mode(kl_ctx *c, uint32_t mode) {
+    if (!c || mode > KL_ACCUM_SUM) return fail(c, KL_E_INVALID, "bad accumulation mode");
+    c->accum_mode = mode;
+    return kl_reset(c);
+}
+kl_status kl_copy_accum_to_device(kl_ctx *c, void *dst, size_t bytes) {
+    if (!c || !dst) return fail(c, KL_E_INVALID, "null destination");
+    if (!c->d_acc.p || c->d_acc.n != c->npl) return fail(c, KL_E_STATE, "nothing rendered yet");
+    if (bytes != (size_t)c->npl * 16) return fail(c, KL_E_INVALID, "size must be local_rows x width x 16 bytes");
+    KL_HIP(c, hipMemcpyAsync(dst, c->d_acc.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    return KL_OK;
+}
+kl_status kl_copy_accum_from_device(kl_ctx *c, const void *src, size_t bytes) {
+    if (!c || !src) return fail(c, KL_E_INVALID, "null source");
+    kl_status s = ensure_buffers(c);
+    if (s != KL_OK) return s;
+    if (bytes != (size_t)c->npl * 16) return fail(c, KL_E_INVALID, "size must be local_rows x width x 16 bytes");
+    KL_HIP(c, hipMemcpyAsync(c->d_acc.p, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    return KL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+// Binned-SAH BVH builder (host, multi-threaded). See kl_bvh.hpp for the guarantees.
+#include "kl_bvh.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <future>
+#include <limits>
+
+#include "kl_types.hpp"
+
+namespace kl {
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::infinity(); hi[k] = -lo[k]; } }
+    void grow(const Box &b) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+    void grow(const float p[3]) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+        return 2.0f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct Prim { Box box; float c[3]; uint32_t type, index; };
+
+struct TmpNode {
+    Box box[2];
+    int32_t child[2];     // >= 0: TmpNode index; < 0: ~leaf index
+};
+struct TmpLeaf { uint32_t type, start, count; };   // range in Builder::prims
+
+constexpr int NBINS = 16;
+constexpr uint32_t LEAF_TARGET = 4;
+
+struct Builder {
+    std::vector<Prim> prims;
+    std::vector<TmpNode> nodes;
+    std::vector<TmpLeaf> leaves;
+    std::atomic<uint32_t> n_nodes{0}, n_leaves{0};
+    std::atomic<int> tasks{0};
+    int max_tasks = 1;
+
+    static uint32_t ceil_log2(uint32_t n) { uint32_t l = 0; while ((1u << l) < n) l++; return l; }
+
+    int32_t make_leaf(uint32_t b, uint32_t e) {
+        uint32_t li = n_leaves.fetch_add(1);
+        leaves[li].type = prims[b].type; leaves[li].start = b; leaves[li].count = e - b;
+        return ~(int32_t)li;
+    }
+    bool single_type(uint32_t b, uint32_t e) const {
+        for (uint32_t i = b + 1; i < e; i++) if (prims[i].type != prims[b].type) return false;
+        return true;
+    }
+    Box bounds(uint32_t b, uint32_t e) const { Box x; x.reset(); for (uint32_t i = b; i < e; i++) x.grow(prims[i].box); return x; }
+
+    // returns the child reference for prims [b, e); `depth` = number of inner nodes above
+    int32_t build(uint32_t b, uint32_t e, int depth) {
+        const uint32_t n = e - b;
+        if (n == 1) return make_leaf(b, e);
+        const bool homo = single_type(b, e);
+        if (n <= LEAF_TARGET && homo) return make_leaf(b, e);
+        uint32_t mid = 0;
+        bool have_split = false;
+        if (n <= LEAF_MAX && !homo) {
+            // small mixed run: separate the types (at most two such levels)
+            uint32_t t0 = prims[b].type;
+            for (uint32_t i = b; i < e; i++) t0 = std::min(t0, prims[i].type);
+            auto it = std::partition(prims.begin() + b, prims.begin() + e, [t0](const Prim &p) { return p.type == t0; });
+            mid = (uint32_t)(it - prims.begin()); have_split = true;
+        }
+        const int rem = BVH_MAX_DEPTH - depth;
+        const bool forced_median = (int)ceil_log2(n) + 2 >= rem;   // out of depth: balanced splits only from here down
+        if (forced_median && n <= LEAF_MAX && homo) return make_leaf(b, e);
+        if (!have_split) {
+            Box cb; cb.reset();
+            for (uint32_t i = b; i < e; i++) cb.grow(prims[i].c);
+            int axis = 0;
+            float ext[3] = { cb.hi[0] - cb.lo[0], cb.hi[1] - cb.lo[1], cb.hi[2] - cb.lo[2] };
+            if (ext[1] > ext[axis]) axis = 1;
+            if (ext[2] > ext[axis]) axis = 2;
+            if (!forced_median && ext[axis] > 0.0f) {
+                float best_cost = std::numeric_limits<float>::infinity(); int best_axis = -1, best_bin = -1;
+                for (int ax = 0; ax < 3; ax++) {
+                    if (!(ext[ax] > 0.0f)) continue;
+                    Box bb[NBINS]; uint32_t bn[NBINS];
+                    for (int k = 0; k < NBINS; k++) { bb[k].reset(); bn[k] = 0; }
+                    const float scale = (float)NBINS / ext[ax];
+                    for (uint32_t i = b; i < e; i++) {
+                        int k = (int)((prims[i].c[ax] - cb.lo[ax]) * scale);
+                        k = k < 0 ? 0 : (k >= NBINS ? NBINS - 1 : k);
+                        bb[k].grow(prims[i].box); bn[k]++;
+                    }
+                    float right_area[NBINS]; uint32_t right_n[NBINS];
+                    Box acc; acc.reset(); uint32_t cnt = 0;
+                    for (int k = NBINS - 1; k > 0; k--) { acc.grow(bb[k]); cnt += bn[k]; right_area[k] = acc.area(); right_n[k] = cnt; }
+                    acc.reset(); cnt = 0;
+                    for (int k = 0; k < NBINS - 1; k++) {
+                        acc.grow(bb[k]); cnt += bn[k];
+                        if (cnt == 0 || right_n[k + 1] == 0) continue;
+                        float cost = acc.area() * (float)cnt + right_area[k + 1] * (float)right_n[k + 1];
+                        if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = k; }
+                    }
+                }
+                if (best_axis >= 0) {
+                    if (n <= LEAF_MAX && homo) {
+                        // SAH termination: leaf cost n*A against one node visit plus the children
+                        float pa = bounds(b, e).area();
+                        if ((float)n * pa <= pa + best_cost) return make_leaf(b, e);
+                    }
+                    const float scale = (float)NBINS / ext[best_axis];
+                    const float lo = cb.lo[best_axis];
+                    const int bax = best_axis, bbin = best_bin;
+                    auto it = std::partition(prims.begin() + b, prims.begin() + e, [=](const Prim &p) {
+                        int k = (int)((p.c[bax] - lo) * scale);
+                        k = k < 0 ? 0 : (k >= NBINS ? NBINS - 1 : k);
+                        return k <= bbin;
+                    });
+                    mid = (uint32_t)(it - prims.begin());
+                    have_split = mid > b && mid < e;
+                }
+            }
+            if (!have_split) {
+                if (n <= LEAF_MAX && homo) return make_leaf(b, e);   // coincident centroids
+                mid = b + n / 2;
+                std::nth_element(prims.begin() + b, prims.begin() + mid, prims.begin() + e,
+                                 [axis](const Prim &x, const Prim &y) { return x.c[axis] < y.c[axis]; });
+            }
+        }
+        uint32_t ni = n_nodes.fetch_add(1);
+        int32_t c0, c1;
+        if (n > 32768 && tasks.load() < max_tasks) {
+            tasks.fetch_add(1);
+            auto fut = std::async(std::launch::async, [this, b, mid, depth]() { return build(b, mid, depth + 1); });
+            c1 = build(mid, e, depth + 1);
+            c0 = fut.get();
+            tasks.fetch_sub(1);
+        } else {
+            c0 = build(b, mid, depth + 1);
+            c1 = build(mid, e, depth + 1);
+        }
+        nodes[ni].child[0] = c0; nodes[ni].child[1] = c1;
+        nodes[ni].box[0] = bounds(b, mid); nodes[ni].box[1] = bounds(mid, e);
+        return (int32_t)ni;
+    }
+};
+
+void prim_box(const float *const *v, int nv, Box &b) {
+    b.reset();
+    for (int i = 0; i < nv; i++) b.grow(v[i]);
+}
+void pad_box(Box &b) {
+    for (int k = 0; k < 3; k++) {
+        float m = std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
+        float pad = 1e-6f + 4e-6f * m;
+        b.lo[k] -= pad; b.hi[k] += pad;
+    }
+}
+
+}  // namespace
+
+void identity_order(uint32_t ns, uint32_t nq, uint32_t nt, HostBVH &out) {
+    out.nodes.clear(); out.root = NODE_DONE;
+    out.sph_order.resize(ns); out.quad_order.resize(nq); out.tri_order.resize(nt);
+    for (uint32_t i = 0; i < ns; i++) out.sph_order[i] = i;
+    for (uint32_t i = 0; i < nq; i++) out.quad_order[i] = i;
+    for (uint32_t i = 0; i < nt; i++) out.tri_order[i] = i;
+    std::memset(&out.stats, 0, sizeof out.stats);
+    out.stats.spheres = ns; out.stats.quads = nq; out.stats.tris = nt;
+}
+
+void build_bvh(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
+               HostBVH &out, unsigned threads) {
+    auto t0 = std::chrono::steady_clock::now();
+    const uint32_t n = ns + nq + nt;
+    identity_order(0, 0, 0, out);
+    out.stats.spheres = ns; out.stats.quads = nq; out.stats.tris = nt;
+    if (n == 0) return;
+    Builder B;
+    B.prims.resize(n);
+    for (uint32_t i = 0; i < ns; i++) {
+        Prim &p = B.prims[i]; p.type = PRIM_SPHERE; p.index = i;
+        for (int k = 0; k < 3; k++) { p.box.lo[k] = s[i].center[k] - s[i].radius; p.box.hi[k] = s[i].center[k] + s[i].radius; }
+    }
+    for (uint32_t i = 0; i < nq; i++) {
+        Prim &p = B.prims[ns + i]; p.type = PRIM_QUAD; p.index = i;
+        const float *v[4] = { q[i].v0, q[i].v1, q[i].v2, q[i].v3 };
+        prim_box(v, 4, p.box);
+    }
+    for (uint32_t i = 0; i < nt; i++) {
+        Prim &p = B.prims[ns + nq + i]; p.type = PRIM_TRI; p.index = i;
+        const float *v[3] = { t[i].v0, t[i].v1, t[i].v2 };
+        prim_box(v, 3, p.box);
+    }
+    for (Prim &p : B.prims) {
+        pad_box(p.box);
+        for (int k = 0; k < 3; k++) p.c[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
+    }
+    B.nodes.resize(n); B.leaves.resize(n);
+    B.max_tasks = threads > 1 ? (int)threads - 1 : 0;
+    int32_t root = B.build(0, n, 0);
+
+    // flatten depth-first; leaves append their primitives to the per-type leaf order
+    const uint32_t nn = B.n_nodes.load();
+    out.nodes.assign((size_t)nn * 16, 0.0f);
+    out.sph_order.reserve(ns); out.quad_order.reserve(nq); out.tri_order.reserve(nt);
+    uint32_t next = 0, max_depth = 0, max_leaf = 0, n_leaves = 0;
+    double sah = 0.0;
+    struct Item { int32_t tmp; int32_t *slot; uint32_t depth; };
+    std::vector<Item> stack;
+    int32_t root_ref = 0;
+    stack.push_back({root, &root_ref, 0});
+    std::vector<int32_t> child_store((size_t)nn * 2);
+    Box rootbox = B.bounds(0, n);
+    const float root_area = std::max(rootbox.area(), 1e-30f);
+    while (!stack.empty()) {
+        Item it = stack.back(); stack.pop_back();
+        if (it.tmp < 0) {
+            const TmpLeaf &lf = B.leaves[(uint32_t)~it.tmp];
+            std::vector<uint32_t> &ord = lf.type == PRIM_SPHERE ? out.sph_order : (lf.type == PRIM_QUAD ? out.quad_order : out.tri_order);
+            uint32_t start = (uint32_t)ord.size();
+            for (uint32_t i = 0; i < lf.count; i++) ord.push_back(B.prims[lf.start + i].index);
+            *it.slot = make_leaf(lf.type, start, lf.count);
+            max_depth = std::max(max_depth, it.depth); max_leaf = std::max(max_leaf, lf.count); n_leaves++;
+            sah += (double)B.bounds(lf.start, lf.start + lf.count).area() / root_area * lf.count;
+        } else {
+            const TmpNode &tn = B.nodes[(uint32_t)it.tmp];
+            uint32_t idx = next++;
+            *it.slot = (int32_t)idx;
+            float *o = &out.nodes[(size_t)idx * 16];
+            o[0] = tn.box[0].lo[0]; o[1] = tn.box[0].lo[1]; o[2] = tn.box[0].lo[2];
+            o[3] = tn.box[0].hi[0]; o[4] = tn.box[0].hi[1]; o[5] = tn.box[0].hi[2];
+            o[6] = tn.box[1].lo[0]; o[7] = tn.box[1].lo[1]; o[8] = tn.box[1].lo[2];
+            o[9] = tn.box[1].hi[0]; o[10] = tn.box[1].hi[1]; o[11] = tn.box[1].hi[2];
+            sah += (double)(tn.box[0].area() + tn.box[1].area()) / root_area * 0.5 * 2.0 * 0.5;  // one visit per entered child box
+            // children are patched in after they get their final index; child 0 is laid out next
+            stack.push_back({tn.child[1], &child_store[(size_t)idx * 2 + 1], it.depth + 1});
+            stack.push_back({tn.child[0], &child_store[(size_t)idx * 2 + 0], it.depth + 1});
+        }
+    }
+    for (uint32_t i = 0; i < nn; i++) {
+        std::memcpy(&out.nodes[(size_t)i * 16 + 12], &child_store[(size_t)i * 2], 4);
+        std::memcpy(&out.nodes[(size_t)i * 16 + 13], &child_store[(size_t)i * 2 + 1], 4);
+    }
+    out.root = root_ref;
+    out.stats.nodes = nn; out.stats.leaves = n_leaves; out.stats.max_depth = max_depth; out.stats.max_leaf_size = max_leaf;
+    out.stats.sah_cost = (float)sah;
+    out.stats.node_bytes = (uint64_t)nn * 64u;
+    out.stats.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace kl

@@ -1,0 +1,32 @@
+// Host-side SAH BVH builder. Output is the flat 64-byte node array and the
+// leaf ordering of every primitive type that the traversal kernel consumes
+// (layout: kl_types.hpp).
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "Math/kl_render.h"
+
+namespace kl {
+
+struct HostBVH {
+    std::vector<float> nodes;            // 16 floats (64 bytes) per node
+    int32_t root;                        // child reference of the whole scene
+    std::vector<uint32_t> sph_order;     // leaf position -> index into the uploaded sphere array
+    std::vector<uint32_t> quad_order;
+    std::vector<uint32_t> tri_order;
+    kl_bvh_stats stats;
+};
+
+// Builds over all primitives. Guarantees: every leaf holds 1..8 primitives of one type; no leaf
+// lies deeper than BVH_MAX_DEPTH inner nodes, so a traversal stack of that many entries cannot
+// overflow; leaf boxes are widened by a few ulps of their coordinates so that rounding in the
+// slab test cannot cull a primitive the exact arithmetic would reach.
+void build_bvh(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
+               HostBVH &out, unsigned threads);
+
+// No tree: identity ordering, root = NODE_DONE (flat-loop kernel only).
+void identity_order(uint32_t ns, uint32_t nq, uint32_t nt, HostBVH &out);
+
+}  // namespace kl

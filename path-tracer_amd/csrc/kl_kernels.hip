@@ -1,0 +1,632 @@
+// Wavefront path-tracing kernels for gfx950 (wave64).
+//
+//   generate  : camera rays for every (frame slot, pixel) of a batch       -> ray queue 0
+//   intersect : closest hit per ray; persistent wave64 workgroups pull ray
+//               ranges from a global counter and refill idle lanes; SAH-BVH
+//               traversal with a per-lane stack in LDS (or a flat loop for
+//               scenes of a few primitives)                                 -> hit records
+//   shade     : surface reconstruction + BSDF / environment / texture; the
+//               surviving rays are compacted with ballot + popcount into the
+//               next queue (or left in place for the separate compact kernel)
+//   compact   : stand-alone stream compaction of a shaded queue
+//   accumulate: running mean (or sum) over the frames of the batch, in order
+//
+// Arithmetic that restates the reference shader (resources/Shaders/RawFrame.glsl,
+// cited as RF:line) keeps its operation order and is compiled unfused.
+#include "kl_kernels.hpp"
+#include "kl_math.hpp"
+
+namespace kl {
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t mask_rank(unsigned long long m) {   // set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// one atomic per wave: reserves popcount(pred) consecutive slots, returns this lane's slot
+__device__ __forceinline__ uint32_t wave_reserve(uint32_t *counter, bool pred) {
+    unsigned long long m = __ballot(pred);
+    if (m == 0ull) return 0u;
+    uint32_t n = (uint32_t)__popcll(m);
+    uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+    uint32_t base = 0u;
+    if (lane_id() == leader) base = atomicAdd(counter, n);
+    base = __shfl(base, (int)leader);
+    return base + mask_rank(m);
+}
+
+__device__ __forceinline__ v3 ldv(const float *p) { return V(p[0], p[1], p[2]); }
+
+// local pixel -> global pixel for the row-band partition
+__device__ __forceinline__ void local_to_pixel(const FrameDev &f, uint32_t li, uint32_t &x, uint32_t &y) {
+    uint32_t ly = li / f.width;
+    x = li - ly * f.width;
+    uint32_t band = ly / f.band_rows;
+    y = (band * f.world + f.rank) * f.band_rows + (ly - band * f.band_rows);
+}
+
+// ------------------------------------------------------------------ intersectors
+// RF:196-216; the field the shader calls Diameter is used as a radius
+__device__ __forceinline__ bool sphere_intersect(v3 o, v3 d, float4 s, float eps, float &t) {
+    v3 oc = o - V(s.x, s.y, s.z);
+    float b = dot(oc, d);
+    float delta = b * b - dot(oc, oc) + s.w * s.w;
+    if (delta < 0.0f) return false;
+    float sq = sqrtf(delta);
+    if (-b - sq > eps) { t = -b - sq; return true; }
+    else if (-b + sq > eps) { t = -b + sq; return true; }
+    return false;
+}
+// RF:218-269 inverse-bilinear patch; uv out = (v, 1-u). May report "hit" with a NaN t,
+// which the caller's comparison rejects exactly as RF:316 does.
+__device__ __forceinline__ bool quad_intersect(v3 o, v3 d, v3 v0, v3 v1, v3 v2, v3 v3_, float &t_out, float &uo, float &vo) {
+    v3 a = v1 - v0, b = v3_ - v0, c = v2 - v0, p = o - v0;
+    v3 nor = cross(a, b);
+    float t = -dot(p, nor) / dot(d, nor);
+    if (t < 0.0f) return false;
+    v3 pos = p + d * t;
+    v3 mor = V(fabsf(nor.x), fabsf(nor.y), fabsf(nor.z));
+    int id = (mor.x > mor.y && mor.x > mor.z) ? 0 : ((mor.y > mor.z) ? 1 : 2);
+    int idu = id == 0 ? 1 : (id == 1 ? 2 : 0);      // Quad_Face[id], RF:44
+    int idv = id == 0 ? 2 : (id == 1 ? 0 : 1);      // Quad_Face[id+1]
+    float kpx = comp(pos, idu), kpy = comp(pos, idv);
+    float kax = comp(a, idu), kay = comp(a, idv);
+    float kbx = comp(b, idu), kby = comp(b, idv);
+    float kcx = comp(c, idu), kcy = comp(c, idv);
+    float kgx = kcx - kbx - kax, kgy = kcy - kby - kay;
+    float k0 = cross2d(kpx, kpy, kbx, kby);
+    float k2 = cross2d(kcx - kbx, kcy - kby, kax, kay);
+    float k1 = cross2d(kpx, kpy, kgx, kgy) - comp(nor, id);
+    float u, v;
+    if (fabsf(k2) < 0.00001f) {
+        v = -k0 / k1;
+        u = cross2d(kpx, kpy, kax, kay) / k1;
+    } else {
+        float w = k1 * k1 - 4.0f * k0 * k2;
+        if (w < 0.0f) return false;
+        w = sqrtf(w);
+        float ik2 = 1.0f / (2.0f * k2);
+        v = (-k1 - w) * ik2;
+        if (v < 0.0f || v > 1.0f) v = (-k1 + w) * ik2;
+        u = (kpx - kax * v) / (kbx + kgx * v);
+    }
+    if (u < 0.0f || u > 1.0f || v < 0.0f || v > 1.0f) return false;
+    t_out = t; uo = v; vo = 1.0f - u;
+    return true;
+}
+// two-sided Moeller-Trumbore on (v0, e1, e2) with explicit fused multiply-adds (no reference counterpart)
+__device__ __forceinline__ bool tri_intersect(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float &t, float &bu, float &bv) {
+    v3 p = fcross(d, e2);
+    float det = fdot(e1, p);
+    float inv = 1.0f / det;
+    v3 s = o - v0;
+    float u = fdot(s, p) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    v3 q = fcross(s, e1);
+    float v = fdot(d, q) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    t = fdot(e2, q) * inv; bu = u; bv = v;
+    return true;
+}
+
+struct Hit { float t; uint32_t ref; float u, v; uint32_t id; };
+
+// acceptance rule of RF:302,316 (`t < best && t > 0.001`); on exactly equal t the lower
+// declaration-order id wins, which is what the shader's in-order loop with a strict `<` does
+__device__ __forceinline__ void accept(Hit &h, float t, uint32_t ref, uint32_t id, float u, float v) {
+    if (t > 0.001f && (t < h.t || (t == h.t && id < h.id))) { h.t = t; h.ref = ref; h.id = id; h.u = u; h.v = v; }
+}
+__device__ __forceinline__ void test_sphere(const SceneDev &sc, uint32_t i, v3 o, v3 d, float eps, Hit &h) {
+    float t;
+    if (sphere_intersect(o, d, sc.sph[i], eps, t)) accept(h, t, make_ref(PRIM_SPHERE, i), sc.sph_id[i], 0.0f, 0.0f);
+}
+__device__ __forceinline__ void test_quad(const SceneDev &sc, uint32_t i, v3 o, v3 d, Hit &h) {
+    float4 a = sc.quad[3 * i], b = sc.quad[3 * i + 1], c = sc.quad[3 * i + 2];
+    float t, u, v;
+    if (quad_intersect(o, d, V(a.x, a.y, a.z), V(a.w, b.x, b.y), V(b.z, b.w, c.x), V(c.y, c.z, c.w), t, u, v))
+        accept(h, t, make_ref(PRIM_QUAD, i), sc.quad_id[i], u, v);
+}
+__device__ __forceinline__ void test_tri(const SceneDev &sc, uint32_t i, v3 o, v3 d, Hit &h) {
+    float4 a = sc.tri[3 * i], b = sc.tri[3 * i + 1], c = sc.tri[3 * i + 2];
+    float t, u, v;
+    if (tri_intersect(o, d, V(a.x, a.y, a.z), V(a.w, b.x, b.y), V(b.z, b.w, c.x), t, u, v))
+        accept(h, t, make_ref(PRIM_TRI, i), __float_as_uint(c.y), u, v);
+}
+__device__ __forceinline__ bool ray_finite(v3 o, v3 d) {
+    const float inf = __builtin_huge_valf();
+    return fabsf(o.x) < inf && fabsf(o.y) < inf && fabsf(o.z) < inf && fabsf(d.x) < inf && fabsf(d.y) < inf && fabsf(d.z) < inf;
+}
+
+// ------------------------------------------------------------------ generate
+// RF:417-422 with the uv arithmetic of RF:428-429,436; one thread per (slot, pixel)
+__global__ __launch_bounds__(256) void k_generate(FrameDev f, RayQueue q, uint32_t *count0) {
+    const uint32_t total = f.nslots * f.npl;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count0 = total;
+    const float rx = (float)f.width, ry = (float)f.height;
+    const float m = fmaxf(rx, ry);
+    const v3 pos = ldv(f.pos), pc = ldv(f.pc), pu = ldv(f.pu), pv = ldv(f.pv);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        uint32_t slot = i / f.npl, li = i - slot * f.npl, x, y;
+        local_to_pixel(f, li, x, y);
+        float ux = (((float)x + 0.5f) - 1.0f - rx / 2.0f) / m;
+        float uy = (((float)y + 0.5f) - 1.0f - ry / 2.0f) / m;
+        if (f.mode != KL_MODE_Z) {               // RF:436 with SPP = 1
+            float psx = 1.0f / rx, psy = 1.0f / ry;
+            ux = (ux - 0.5f * psx) + (0.0f / 1.0f) * psx;
+            uy = (uy - 0.5f * psy) + (0.0f / 1.0f) * psy;
+        }
+        v3 d = normalize(pc + pu * ux + pv * uy - pos);
+        q.od[i] = make_float4(pos.x, pos.y, pos.z, d.x);
+        q.d2[i] = make_float2(d.y, d.z);
+        q.tp[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(i));
+    }
+}
+
+// ------------------------------------------------------------------ intersect: flat loop
+// RF:294-328 for scenes of a few primitives: every lane walks the same primitive list, so the
+// geometry comes through uniform (scalar) loads and nothing but the ray and hit touch memory.
+__global__ __launch_bounds__(256) void k_intersect_brute(SceneDev sc, FrameDev f, RayQueue q, float4 *hits,
+                                                         const uint32_t *count_ptr, Counters *cn) {
+    const uint32_t count = *count_ptr;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(&cn->rays, (unsigned long long)count);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        float4 od = q.od[i]; float2 d2 = q.d2[i];
+        v3 o = V(od.x, od.y, od.z), d = V(od.w, d2.x, d2.y);
+        Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
+        if (ray_finite(o, d)) {
+            for (uint32_t k = 0; k < sc.ns; k++) test_sphere(sc, k, o, d, f.eps, h);
+            for (uint32_t k = 0; k < sc.nq; k++) test_quad(sc, k, o, d, h);
+            for (uint32_t k = 0; k < sc.nt; k++) test_tri(sc, k, o, d, h);
+        }
+        hits[i] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
+    }
+}
+
+// ------------------------------------------------------------------ intersect: BVH
+constexpr uint32_t ISECT_WAVES = 4;          // waves per workgroup
+constexpr uint32_t ISECT_CHUNK = 256;        // rays a wave takes from the global counter at a time
+constexpr uint32_t ISECT_REFILL = 40;        // refill idle lanes when fewer than this many are active
+
+template <bool STATS>
+__global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc, FrameDev f, RayQueue q, float4 *hits,
+                                                                   const uint32_t *count_ptr, uint32_t *head, Counters *cn) {
+    // per-lane traversal stack: entry e of lane l of wave w at [w][e][l] -> consecutive lanes hit consecutive banks
+    __shared__ int stack[ISECT_WAVES][BVH_MAX_DEPTH][64];
+    const uint32_t lane = lane_id();
+    int *st = &stack[threadIdx.x >> 6][0][lane];
+    const uint32_t count = *count_ptr;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(&cn->rays, (unsigned long long)count);
+
+    uint32_t cur = 0, end = 0;               // wave-uniform: rays [cur, end) reserved by this wave
+    bool exhausted = false;                  // wave-uniform: the global counter has run past count
+    bool active = false;
+    uint32_t ray = 0; int node = NODE_DONE; int sp = 0;
+    v3 o = V(0, 0, 0), d = V(0, 0, 0), id = V(0, 0, 0), nood = V(0, 0, 0);
+    Hit h; h.t = 0; h.ref = REF_MISS; h.u = h.v = 0; h.id = 0xFFFFFFFFu;
+    unsigned long long s_nodes = 0, s_sph = 0, s_quad = 0, s_tri = 0, s_act = 0, s_tot = 0;
+
+    for (;;) {
+        // ---- refill idle lanes from the wave's reserved range
+        unsigned long long idle = __ballot(!active);
+        if (idle != 0ull && !(exhausted && cur == end)) {
+            if (cur == end) {
+                uint32_t base = 0u;
+                if (lane == 0) base = atomicAdd(head, ISECT_CHUNK);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= count) { exhausted = true; }
+                else { cur = base; end = min(base + ISECT_CHUNK, count); }
+            }
+            uint32_t avail = end - cur;
+            uint32_t want = (uint32_t)__popcll(idle);
+            uint32_t take = min(avail, want);
+            uint32_t r = mask_rank(idle);
+            if (!active && r < take) {
+                ray = cur + r;
+                float4 od = q.od[ray]; float2 d2 = q.d2[ray];
+                o = V(od.x, od.y, od.z); d = V(od.w, d2.x, d2.y);
+                h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
+                // slab reciprocals; a zero component is nudged so 0 * inf never appears
+                float sx = fabsf(d.x) > 1e-20f ? d.x : copysignf(1e-20f, d.x);
+                float sy = fabsf(d.y) > 1e-20f ? d.y : copysignf(1e-20f, d.y);
+                float sz = fabsf(d.z) > 1e-20f ? d.z : copysignf(1e-20f, d.z);
+                id = V(1.0f / sx, 1.0f / sy, 1.0f / sz);
+                nood = V(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
+                sp = 0;
+                node = ray_finite(o, d) ? sc.root : NODE_DONE;   // a NaN ray hits nothing (as in the flat loop)
+                active = true;
+            }
+            cur += take;
+        }
+        unsigned long long am = __ballot(active);
+        if (am == 0ull) { if (exhausted && cur == end) break; else continue; }
+        const uint32_t thresh = (exhausted && cur == end) ? 1u : ISECT_REFILL;
+
+        // ---- traverse until too few lanes are busy
+        do {
+            if (active) {
+                if (node == NODE_DONE) {
+                    hits[ray] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
+                    active = false;
+                } else if (node >= 0) {
+                    const float4 *np = sc.nodes + 4u * (uint32_t)node;
+                    float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                    if (STATS) s_nodes++;
+                    float ax0 = fmaf(n0.x, id.x, nood.x), ax1 = fmaf(n0.w, id.x, nood.x);
+                    float ay0 = fmaf(n0.y, id.y, nood.y), ay1 = fmaf(n1.x, id.y, nood.y);
+                    float az0 = fmaf(n0.z, id.z, nood.z), az1 = fmaf(n1.y, id.z, nood.z);
+                    float t0n = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.0f));
+                    float t0f = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), h.t));
+                    float bx0 = fmaf(n1.z, id.x, nood.x), bx1 = fmaf(n2.y, id.x, nood.x);
+                    float by0 = fmaf(n1.w, id.y, nood.y), by1 = fmaf(n2.z, id.y, nood.y);
+                    float bz0 = fmaf(n2.x, id.z, nood.z), bz1 = fmaf(n2.w, id.z, nood.z);
+                    float t1n = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.0f));
+                    float t1f = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), h.t));
+                    bool hit0 = t0n <= t0f, hit1 = t1n <= t1f;
+                    int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                    if (hit0 && hit1) {
+                        bool swap = t1n < t0n;
+                        int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                        st[sp * 64] = farc; sp++;
+                        node = nearc;
+                    } else if (hit0) node = c0;
+                    else if (hit1) node = c1;
+                    else if (sp > 0) { sp--; node = st[sp * 64]; }
+                    else node = NODE_DONE;
+                } else {
+                    uint32_t lv = (uint32_t)~node;
+                    uint32_t start = lv & 0x3FFFFFFu, cnt = ((lv >> 26) & 7u) + 1u, type = (lv >> 29) & 3u;
+                    if (type == PRIM_TRI) {
+                        for (uint32_t k = 0; k < cnt; k++) test_tri(sc, start + k, o, d, h);
+                        if (STATS) s_tri += cnt;
+                    } else if (type == PRIM_SPHERE) {
+                        for (uint32_t k = 0; k < cnt; k++) test_sphere(sc, start + k, o, d, f.eps, h);
+                        if (STATS) s_sph += cnt;
+                    } else {
+                        for (uint32_t k = 0; k < cnt; k++) test_quad(sc, start + k, o, d, h);
+                        if (STATS) s_quad += cnt;
+                    }
+                    if (sp > 0) { sp--; node = st[sp * 64]; }
+                    else node = NODE_DONE;
+                }
+            }
+            am = __ballot(active);
+            if (STATS) { s_act += (unsigned long long)__popcll(am); s_tot += 64ull; }
+        } while ((uint32_t)__popcll(am) >= thresh);
+    }
+    if (STATS) {
+        // lane sums -> one atomic per wave per counter
+        for (int off = 32; off > 0; off >>= 1) {
+            s_nodes += __shfl_down(s_nodes, off); s_sph += __shfl_down(s_sph, off);
+            s_quad += __shfl_down(s_quad, off); s_tri += __shfl_down(s_tri, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&cn->nodes, s_nodes); atomicAdd(&cn->sphere_tests, s_sph);
+            atomicAdd(&cn->quad_tests, s_quad); atomicAdd(&cn->tri_tests, s_tri);
+            atomicAdd(&cn->lane_active, s_act); atomicAdd(&cn->lane_total, s_tot);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ shading helpers
+struct Surf { v3 pos, n; bool inside; uint32_t mat; float u, v; };
+
+// the fields of the shader's Hit struct (RF:142-150) that shading reads, rebuilt from (ray, t, ref)
+__device__ __forceinline__ Surf surface(const SceneDev &sc, v3 o, v3 d, float t, uint32_t ref, float hu, float hv) {
+    Surf s;
+    s.pos = o + d * t;                                             // RF:304,318
+    uint32_t i = ref_index(ref), type = ref_type(ref);
+    if (type == PRIM_SPHERE) {
+        float4 sp = sc.sph[i];
+        v3 c = V(sp.x, sp.y, sp.z);
+        s.n = normalize(s.pos - c);                                // RF:305
+        s.inside = length(o - c) <= sp.w;                          // RF:308
+        if (s.inside) s.n = s.n * -1.0f;                           // RF:309
+        s.mat = sc.sph_mat[i]; s.u = 0.0f; s.v = 0.0f;
+    } else if (type == PRIM_QUAD) {
+        float4 a = sc.quad[3 * i], b = sc.quad[3 * i + 1], c = sc.quad[3 * i + 2];
+        v3 v1 = V(a.w, b.x, b.y), v2 = V(b.z, b.w, c.x), v3_ = V(c.y, c.z, c.w);
+        v3 nor = normalize(cross(v2 - v1, v3_ - v1));              // RF:319
+        s.n = dot(nor, d) < 0.0f ? nor : -nor;                     // faceforward, RF:320
+        s.inside = false; s.mat = sc.quad_mat[i]; s.u = hu; s.v = hv;
+    } else {
+        float4 a = sc.tri[3 * i], b = sc.tri[3 * i + 1], c = sc.tri[3 * i + 2];
+        v3 e1 = V(a.w, b.x, b.y), e2 = V(b.z, b.w, c.x);
+        v3 nor = normalize(cross(e1, e2));
+        s.n = dot(nor, d) < 0.0f ? nor : -nor;
+        s.inside = false;
+        float4 s0 = sc.tri_shade[2 * i], s1 = sc.tri_shade[2 * i + 1];
+        s.mat = __float_as_uint(s1.z);
+        float w = (1.0f - hu) - hv;
+        s.u = (s0.x * w + s0.z * hu) + s1.x * hv;
+        s.v = (s0.y * w + s0.w * hu) + s1.y * hv;
+    }
+    return s;
+}
+
+// texture(sampler, uv).rgb with the sampler state of source/Rendering/Opengl/Texture.cpp:8-12:
+// NEAREST, clamp to edge, rows as uploaded; a NaN coordinate selects texel 0
+__device__ __forceinline__ v3 tex_fetch(const SceneDev &sc, int which, float u, float v) {
+    uint32_t w = sc.tex_w[which], hgt = sc.tex_h[which];
+    float fx = floorf(u * (float)w), fy = floorf(v * (float)hgt);
+    uint32_t ix = !(fx >= 0.0f) ? 0u : (fx >= (float)w ? w - 1u : (uint32_t)fx);
+    uint32_t iy = !(fy >= 0.0f) ? 0u : (fy >= (float)hgt ? hgt - 1u : (uint32_t)fy);
+    uchar4 px = sc.tex[which][(size_t)iy * w + ix];
+    const float k = 1.0f / 255.0f;
+    return V((float)px.x * k, (float)px.y * k, (float)px.z * k);
+}
+// RF:330-339 with eulerToRot(0,-90,0) (RF:98-122) folded: d' = (d.x, c*d.y + s*d.z, -s*d.y + c*d.z)
+__device__ __forceinline__ v3 environment(const SceneDev &sc, const FrameDev &f, v3 d) {
+    const float c = -4.371138828673793e-08f, sn = -1.0f;
+    float rx = (1.0f * d.x + 0.0f * d.y) + 0.0f * d.z;
+    float ry = (0.0f * d.x + c * d.y) + sn * d.z;
+    float rz = (0.0f * d.x + (-sn) * d.y) + c * d.z;
+    float phi = atan2f_(ry, rx);
+    float theta = acosf_(rz);
+    float u = phi / 6.28318530718f + 0.5f;
+    float v = theta / 3.14159265359f;
+    return tex_fetch(sc, KL_TEX_HDRI, u, v) * f.hdri_strength;
+}
+// RF:273-277
+__device__ __forceinline__ v3 hemisphere(f4 r) {
+    float px = 2.0f * 3.14159265359f * r.x;
+    float py = sqrtf(r.y);
+    return normalize(V(sinf_(px) * py, cosf_(px) * py, sqrtf(1.0f - py * py)));
+}
+// RF:279-292
+__device__ __forceinline__ v3 cone_roughness(v3 dir, float theta, f4 r) {
+    v3 left = cross(dir, V(0.0f, 1.0f, 0.0f));
+    left = length(left) > 0.1f ? normalize(left) : normalize(cross(dir, V(0.0f, 0.0f, 1.0f)));
+    v3 up = normalize(cross(dir, left));
+    float cos_theta = (1.0f - r.x) + r.x * cosf_(theta);
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float phi = r.y * 2.0f * 3.14159265359f;
+    return normalize(left * cosf_(phi) * sin_theta + up * sinf_(phi) * sin_theta + dir * cos_theta);
+}
+// RF:87-96
+__device__ __forceinline__ float snell(float sin_theta, float iori, float iort) { return iori / iort * sin_theta; }
+__device__ __forceinline__ float fresnel(float iori, float iort, float cosi, float cost) {
+    float rpar = (iort * cosi - iori * cost) / (iort * cosi + iori * cost);
+    float rper = (iori * cosi - iort * cost) / (iori * cosi + iort * cost);
+    rpar *= rpar; rper *= rper;
+    return (rpar + rper) / 2.0f;
+}
+
+constexpr uint32_t PATH_DEAD = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------------ shade
+// One lane per traced ray. MODE selects the walk: RF:355-407 (path traced), RF:341-353 (AO),
+// RF:409-415 (ZDepth). A finished path writes its colour to raw[path]; a continuing one is
+// pushed to qout (fused compaction) or written back in place for k_compact.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue qin, const float4 *hits,
+                                               const uint32_t *count_in, RayQueue qout, uint32_t *count_out,
+                                               float4 *raw, uint32_t bounce, uint32_t fused) {
+    const uint32_t count = *count_in;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    for (uint32_t base = wave * 64u; base < count; base += nwaves * 64u) {
+        const uint32_t i = base + lane_id();
+        const bool valid = i < count;
+        bool alive = false;
+        v3 o = V(0, 0, 0), d = V(0, 0, 0), thr = V(0, 0, 0);
+        uint32_t path = PATH_DEAD;
+        if (valid) {
+            float4 od = qin.od[i]; float2 d2 = qin.d2[i]; float4 tp = qin.tp[i]; float4 hr = hits[i];
+            o = V(od.x, od.y, od.z); d = V(od.w, d2.x, d2.y); thr = V(tp.x, tp.y, tp.z);
+            path = __float_as_uint(tp.w);
+            const float t = hr.x; const uint32_t ref = __float_as_uint(hr.y);
+            uint32_t slot = path / f.npl, li = path - slot * f.npl, px, py;
+            local_to_pixel(f, li, px, py);
+            f4 r = rand4(px, py, f.first_frame + slot);
+            v3 col = V(0, 0, 0);
+            bool done = true;
+            if (MODE == KL_MODE_Z) {
+                if (!(t >= f.max_dist)) { float z = 1.0f - fminf(t / 50.0f, 0.9f); col = V(z, z, z); }
+            } else if (MODE == KL_MODE_AO) {
+                if (!(t >= f.max_dist)) {
+                    if (bounce == 0) {
+                        Surf s = surface(sc, o, d, t, ref, hr.z, hr.w);
+                        d = cone_roughness(s.n, 10.0f, r);            // RF:348: theta is 10 radians
+                        o = s.pos + d * f.eps;                        // RF:349
+                        done = false;
+                    } else {
+                        float dist = fminf(t / f.ao_length, 1.0f);    // RF:350
+                        col = V(dist, dist, dist);
+                    }
+                }
+            } else {
+                if (t >= f.max_dist) {
+                    col = thr * environment(sc, f, d);                // RF:362-364
+                } else {
+                    Surf s = surface(sc, o, d, t, ref, hr.z, hr.w);
+                    float4 m0 = sc.mats[2 * s.mat], m1 = sc.mats[2 * s.mat + 1];
+                    const int mtype = __float_as_int(m0.x);
+                    const v3 mcol = V(m0.y, m0.z, m0.w);
+                    if (mtype == KL_DIFFUSE || mtype == KL_TEXTURED) {           // RF:365-378
+                        if (mtype == KL_TEXTURED) {
+                            col = thr * tex_fetch(sc, KL_TEX_ALBEDO, s.u, s.v);
+                        } else {
+                            v3 tangent = normalize(cross(d, s.n));
+                            v3 bitangent = normalize(cross(s.n, tangent));
+                            v3 nl = hemisphere(r);
+                            v3 local = normalize(tangent * nl.x + bitangent * nl.y + s.n * nl.z);
+                            d = normalize(mix(reflect(d, s.n), local, m1.y));
+                            thr = thr * mcol;
+                            done = false;
+                        }
+                    } else if (mtype == KL_GLASS) {                               // RF:379-400
+                        float cosi = fabsf(dot(s.n, d));
+                        float sini = sqrtf(1.0f - cosi * cosi);
+                        float iort = m1.z, iori = 1.0f;
+                        if (s.inside) { iori = iort; iort = 1.0f; }
+                        float sint = snell(sini, iori, iort);
+                        float cost = sqrtf(1.0f - sint * sint);       // NaN past the critical angle: no TIR branch
+                        float frsn = fresnel(iori, iort, cosi, cost);
+                        if (r.x > frsn) {                             // false for NaN -> reflect
+                            v3 bit = normalize(d - s.n * dot(s.n, d));
+                            d = normalize(bit * sint - s.n * cost);
+                            thr = thr * mcol;
+                        } else {
+                            d = reflect(d, s.n);
+                        }
+                        done = false;
+                    } else if (mtype == KL_EMISSIVE) {                            // RF:401-403
+                        col = thr * mcol * m1.x;
+                    } else {
+                        done = false;                                 // unknown type: the shader's if-chain falls through
+                    }
+                    if (!done) o = s.pos + d * f.eps;                 // RF:404
+                }
+                if (!done && bounce + 1 >= f.max_bounces) { done = true; col = V(0, 0, 0); }   // RF:406
+            }
+            if (done) raw[path] = make_float4(col.x, col.y, col.z, 1.0f);
+            alive = !done;
+        }
+        if (fused) {
+            uint32_t slot_out = wave_reserve(count_out, alive);
+            if (alive) {
+                qout.od[slot_out] = make_float4(o.x, o.y, o.z, d.x);
+                qout.d2[slot_out] = make_float2(d.y, d.z);
+                qout.tp[slot_out] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(path));
+            }
+        } else if (valid) {
+            qin.od[i] = make_float4(o.x, o.y, o.z, d.x);
+            qin.d2[i] = make_float2(d.y, d.z);
+            qin.tp[i] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(alive ? path : PATH_DEAD));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ compact
+// stream compaction of a shaded queue: ballot + popcount, one atomic per wave
+__global__ __launch_bounds__(256) void k_compact(RayQueue qin, const uint32_t *count_in, RayQueue qout, uint32_t *count_out) {
+    const uint32_t count = *count_in;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    for (uint32_t base = wave * 64u; base < count; base += nwaves * 64u) {
+        const uint32_t i = base + lane_id();
+        float4 tp = make_float4(0, 0, 0, 0);
+        bool alive = false;
+        if (i < count) { tp = qin.tp[i]; alive = __float_as_uint(tp.w) != PATH_DEAD; }
+        uint32_t dst = wave_reserve(count_out, alive);
+        if (alive) { qout.od[dst] = qin.od[i]; qout.d2[dst] = qin.d2[i]; qout.tp[dst] = tp; }
+    }
+}
+
+// ------------------------------------------------------------------ accumulate
+// resources/Shaders/Accumulation.glsl:16-24 applied to the frames of the batch in order.
+// A frame at or past max_frames contributes the accumulation texel itself (RF:426,461-463).
+__global__ __launch_bounds__(256) void k_accumulate(FrameDev f, const float4 *raw, float4 *acc, float4 *last_raw,
+                                                    uint32_t camera_change, uint32_t accum_mode) {
+    for (uint32_t li = blockIdx.x * blockDim.x + threadIdx.x; li < f.npl; li += gridDim.x * blockDim.x) {
+        float4 a = acc[li];
+        float4 r = make_float4(0, 0, 0, 1);
+        for (uint32_t s = 0; s < f.nslots; s++) {
+            const uint32_t frame = f.first_frame + s;
+            const bool frozen = f.max_frames != 0u && frame >= f.max_frames;
+            r = frozen ? a : raw[(size_t)s * f.npl + li];
+            if (accum_mode == KL_ACCUM_SUM) {
+                a.x += r.x; a.y += r.y; a.z += r.z; a.w = 1.0f;
+            } else if (frame <= 1u || !(camera_change && s == 0u)) {
+                float w = (float)frame;
+                a.x = (a.x * w + r.x) / (w + 1.0f);
+                a.y = (a.y * w + r.y) / (w + 1.0f);
+                a.z = (a.z * w + r.z) / (w + 1.0f);
+                a.w = 1.0f;
+            } else {
+                a = r;
+            }
+        }
+        acc[li] = a;
+        last_raw[li] = r;
+    }
+}
+
+// resources/Shaders/PostProcess.glsl:34-39: CLAMP is what line 38 hands to the 8-bit backbuffer,
+// ACES evaluates the overwritten lines 35-37
+__global__ __launch_bounds__(256) void k_resolve(const float4 *acc, uchar4 *out, uint32_t n, uint32_t tonemap) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 c = acc[i];
+        if (tonemap == KL_TONEMAP_ACES) {
+            float x = fmaxf(c.x, 0.0f), y = fmaxf(c.y, 0.0f), z = fmaxf(c.z, 0.0f);
+            float r = (3.2404542f * x + -1.5371385f * y) + -0.4985314f * z;
+            float g = (-0.9692660f * x + 1.8760108f * y) + 0.0415560f * z;
+            float b = (0.0556434f * x + -0.2040259f * y) + 1.0572252f * z;
+            r = fmaxf(r, 0.0f); g = fmaxf(g, 0.0f); b = fmaxf(b, 0.0f);
+            c.x = (r * (2.51f * r + 0.03f)) / (r * (2.43f * r + 0.59f) + 0.14f);
+            c.y = (g * (2.51f * g + 0.03f)) / (g * (2.43f * g + 0.59f) + 0.14f);
+            c.z = (b * (2.51f * b + 0.03f)) / (b * (2.43f * b + 0.59f) + 0.14f);
+            c.w = 1.0f;
+        }
+        float v[4] = {c.x, c.y, c.z, c.w};
+        unsigned char o[4];
+        for (int k = 0; k < 4; k++) {
+            float q = v[k];
+            q = !(q >= 0.0f) ? 0.0f : (q > 1.0f ? 1.0f : q);
+            o[k] = (unsigned char)(q * 255.0f + 0.5f);
+        }
+        out[i] = make_uchar4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// unpack hit records of kl_trace_rays into (t, declaration-order id, uv)
+__global__ void k_unpack_hits(SceneDev sc, const float4 *hits, uint32_t n, float *t, uint32_t *prim, float2 *uv) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 h = hits[i];
+    uint32_t ref = __float_as_uint(h.y), id = 0xFFFFFFFFu;
+    if (ref != REF_MISS) {
+        uint32_t k = ref_index(ref), type = ref_type(ref);
+        id = type == PRIM_SPHERE ? sc.sph_id[k] : (type == PRIM_QUAD ? sc.quad_id[k] : __float_as_uint(sc.tri[3 * k + 2].y));
+    }
+    t[i] = h.x; prim[i] = id; uv[i] = make_float2(h.z, h.w);
+}
+
+// ------------------------------------------------------------------ launch wrappers
+static inline uint32_t grid_for(uint32_t n, uint32_t cap) {
+    uint32_t g = (n + 255u) / 256u;
+    return g < 1u ? 1u : (g > cap ? cap : g);
+}
+
+void launch_generate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue q, uint32_t *count0) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(f.nslots * f.npl, lc.cus * 8u)), dim3(256), 0, s, f, q, count0);
+}
+void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q, float4 *hits,
+                      const uint32_t *count, uint32_t *head, Counters *cn, bool bvh, bool stats, uint32_t max_rays) {
+    if (!bvh) {
+        hipLaunchKernelGGL(k_intersect_brute, dim3(grid_for(max_rays, lc.cus * 8u)), dim3(256), 0, s, sc, f, q, hits, count, cn);
+        return;
+    }
+    uint32_t blocks = lc.cus * lc.isect_blocks_per_cu;
+    uint32_t need = (max_rays + ISECT_CHUNK - 1u) / ISECT_CHUNK;          // one wave per chunk is already enough
+    need = (need + ISECT_WAVES - 1u) / ISECT_WAVES;
+    if (blocks > need) blocks = need < 1u ? 1u : need;
+    if (stats) hipLaunchKernelGGL(k_intersect_bvh<true>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, count, head, cn);
+    else hipLaunchKernelGGL(k_intersect_bvh<false>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, count, head, cn);
+}
+void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin, const float4 *hits,
+                  const uint32_t *count_in, RayQueue qout, uint32_t *count_out, float4 *raw, uint32_t bounce, bool fused,
+                  uint32_t max_rays) {
+    dim3 g(grid_for(max_rays, lc.cus * 8u)), b(256);
+    uint32_t fu = fused ? 1u : 0u;
+    if (f.mode == KL_MODE_PT) hipLaunchKernelGGL(k_shade<KL_MODE_PT>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu);
+    else if (f.mode == KL_MODE_AO) hipLaunchKernelGGL(k_shade<KL_MODE_AO>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu);
+    else hipLaunchKernelGGL(k_shade<KL_MODE_Z>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu);
+}
+void launch_compact(hipStream_t s, const LaunchCfg &lc, RayQueue qin, const uint32_t *count_in, RayQueue qout, uint32_t *count_out,
+                    uint32_t max_rays) {
+    hipLaunchKernelGGL(k_compact, dim3(grid_for(max_rays, lc.cus * 8u)), dim3(256), 0, s, qin, count_in, qout, count_out);
+}
+void launch_accumulate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, const float4 *raw, float4 *acc, float4 *last_raw,
+                       bool camera_change, uint32_t accum_mode) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(f.npl, lc.cus * 8u)), dim3(256), 0, s, f, raw, acc, last_raw,
+                       camera_change ? 1u : 0u, accum_mode);
+}
+void launch_resolve(hipStream_t s, const LaunchCfg &lc, const float4 *acc, uchar4 *out, uint32_t n, uint32_t tonemap) {
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(n, lc.cus * 8u)), dim3(256), 0, s, acc, out, n, tonemap);
+}
+void launch_unpack_hits(hipStream_t s, const SceneDev &sc, const float4 *hits, uint32_t n, float *t, uint32_t *prim, float2 *uv) {
+    hipLaunchKernelGGL(k_unpack_hits, dim3((n + 255u) / 256u), dim3(256), 0, s, sc, hits, n, t, prim, uv);
+}
+
+}  // namespace kl

@@ -1,0 +1,27 @@
+// Host-callable launchers of the render kernels (kl_kernels.hip).
+#pragma once
+
+#include "Math/kl_render.h"
+#include "kl_types.hpp"
+
+namespace kl {
+
+struct LaunchCfg {
+    uint32_t cus;                    // compute units of the device
+    uint32_t isect_blocks_per_cu;    // resident traversal workgroups per CU (bounded by LDS and VGPRs)
+};
+
+void launch_generate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue q, uint32_t *count0);
+void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q, float4 *hits,
+                      const uint32_t *count, uint32_t *head, Counters *cn, bool bvh, bool stats, uint32_t max_rays);
+void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin, const float4 *hits,
+                  const uint32_t *count_in, RayQueue qout, uint32_t *count_out, float4 *raw, uint32_t bounce, bool fused,
+                  uint32_t max_rays);
+void launch_compact(hipStream_t s, const LaunchCfg &lc, RayQueue qin, const uint32_t *count_in, RayQueue qout,
+                    uint32_t *count_out, uint32_t max_rays);
+void launch_accumulate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, const float4 *raw, float4 *acc, float4 *last_raw,
+                       bool camera_change, uint32_t accum_mode);
+void launch_resolve(hipStream_t s, const LaunchCfg &lc, const float4 *acc, uchar4 *out, uint32_t n, uint32_t tonemap);
+void launch_unpack_hits(hipStream_t s, const SceneDev &sc, const float4 *hits, uint32_t n, float *t, uint32_t *prim, float2 *uv);
+
+}  // namespace kl

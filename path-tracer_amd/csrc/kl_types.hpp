@@ -1,0 +1,79 @@
+// Device-side data layout shared by the kernels (kl_kernels.hip), the BVH
+// builder (kl_bvh.cpp) and the C-ABI implementation (kl_api.cpp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kl {
+
+// ---- primitive references ---------------------------------------------------
+// A hit names its primitive by (type, index into that type's leaf-ordered array).
+enum : uint32_t { PRIM_SPHERE = 0, PRIM_QUAD = 1, PRIM_TRI = 2 };
+constexpr uint32_t REF_MISS = 0xFFFFFFFFu;
+__host__ __device__ inline uint32_t make_ref(uint32_t type, uint32_t index) { return (type << 30) | index; }
+__host__ __device__ inline uint32_t ref_type(uint32_t r) { return r >> 30; }
+__host__ __device__ inline uint32_t ref_index(uint32_t r) { return r & 0x3FFFFFFFu; }
+
+// ---- BVH node: 64 bytes, 64-byte aligned, four float4 -------------------------
+//   q0 = (lo0.x, lo0.y, lo0.z, hi0.x)   q1 = (hi0.y, hi0.z, lo1.x, lo1.y)
+//   q2 = (lo1.z, hi1.x, hi1.y, hi1.z)   q3 = (child0, child1, 0, 0) as int bits
+// child >= 0: index of an inner node. child < 0: leaf, ~child =
+//   (type << 29) | ((count-1) << 26) | start, a run of `count` (1..8) primitives
+//   of one type starting at `start` in that type's leaf-ordered array.
+constexpr int NODE_DONE = 0x7FFFFFFF;       // "stack empty" marker, never a valid node index
+constexpr uint32_t LEAF_MAX = 8;
+__host__ __device__ inline int make_leaf(uint32_t type, uint32_t start, uint32_t count) {
+    return ~(int)((type << 29) | ((count - 1u) << 26) | start);
+}
+constexpr uint32_t MAX_PRIMS_PER_TYPE = 1u << 26;
+constexpr int BVH_MAX_DEPTH = 32;           // builder guarantee == traversal stack entries per lane
+
+struct SceneDev {
+    const float4 *nodes;     // 4 per node
+    int32_t root;            // child reference of the whole scene (node index or leaf), NODE_DONE if empty
+    uint32_t n_nodes;
+    // geometry, leaf order
+    const float4 *sph;       // (cx, cy, cz, r)
+    const float4 *quad;      // 3 per quad: (v0.xyz, v1.x) (v1.yz, v2.xy) (v2.z, v3.xyz)
+    const float4 *tri;       // 3 per tri:  (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, id bits, 0, 0)
+    const uint32_t *sph_id;  // declaration-order primitive id (spheres, then quads, then tris)
+    const uint32_t *quad_id;
+    // shading data, leaf order
+    const uint32_t *sph_mat;
+    const uint32_t *quad_mat;
+    const float4 *tri_shade; // 2 per tri: (uv0.xy, uv1.xy) (uv2.xy, material bits, 0)
+    const float4 *mats;      // 2 per material: (type bits, r, g, b) (emissive, roughness, ior, 0)
+    uint32_t ns, nq, nt, nm;
+    // textures, RGBA8, rows as uploaded
+    const uchar4 *tex[2];
+    uint32_t tex_w[2], tex_h[2];
+};
+
+// ---- per-batch uniforms ---------------------------------------------------------
+struct FrameDev {
+    float pos[3], pc[3], pu[3], pv[3];  // camera position and projection frame (RawFrame.glsl:418-420)
+    uint32_t width, height;             // full image
+    uint32_t npl;                       // pixels owned by this context (local rows x width)
+    uint32_t rank, world, band_rows;    // row-band partition
+    uint32_t mode;
+    uint32_t first_frame, nslots;       // frames [first_frame, first_frame + nslots) are in flight
+    uint32_t max_bounces, max_frames;
+    float eps, max_dist, ao_length, hdri_strength;
+};
+
+// ---- wavefront queues -------------------------------------------------------------
+// One ray = 40 bytes over three arrays so that every access is a full-width vector load:
+//   od[i] = (o.x, o.y, o.z, d.x)   d2[i] = (d.y, d.z)   tp[i] = (throughput rgb, path id bits)
+// path id = slot * npl + local pixel; it also indexes the raw-frame buffer.
+struct RayQueue {
+    float4 *od;
+    float2 *d2;
+    float4 *tp;
+};
+// hit[i] = (t, ref bits, u, v) for ray i of the queue that was traced
+struct Counters {            // 64-bit device counters, see kl_counters
+    unsigned long long rays, nodes, sphere_tests, quad_tests, tri_tests, lane_active, lane_total, pad;
+};
+
+}  // namespace kl

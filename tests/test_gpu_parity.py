@@ -1,0 +1,221 @@
+"""GPU suite: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bar: the kernels restate the same fp32 operation sequence as the oracle (including its
+sin/cos/atan/acos), so images are compared BIT FOR BIT against the oracle; against the
+llvmpipe goldens the tolerances of tests/test_oracle_golden.py apply.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import klrender as kl
+import kloracle as ko
+from conftest import frac_within_rel, golden, mae_clamped
+
+pytestmark = pytest.mark.gpu
+
+KO_MODE = {kl.MODE_AO: ko.MODE_AO, kl.MODE_PT: ko.MODE_PT, kl.MODE_Z: ko.MODE_Z}
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bitexact(a, b, what=""):
+    a, b = bits(a), bits(b)
+    if not np.array_equal(a, b):
+        bad = np.argwhere(a != b)
+        raise AssertionError("%s: %d of %d values differ, first at %s: %r vs %r" % (
+            what, len(bad), a.size, bad[0], a.view(np.float32)[tuple(bad[0])], b.view(np.float32)[tuple(bad[0])]))
+
+
+def make_renderer(w, h, textures=None, **params):
+    r = kl.Renderer(w, h)
+    r.load_builtin_scene()
+    if textures is not None:
+        r.upload_texture(kl.TEX_HDRI, textures["hdri"])
+        r.upload_texture(kl.TEX_ALBEDO, textures["albedo"])
+    if params:
+        r.update_params(**params)
+    return r
+
+
+def render_raw(r, mode, frame):
+    r.set_mode(mode)
+    r.render_frames(1, first_frame=frame)
+    return r.read_raw()
+
+
+@pytest.mark.parametrize("size", [(64, 36), (160, 90), (333, 187), (1, 1), (7, 300)])
+@pytest.mark.parametrize("accel", [kl.ACCEL_BRUTE, kl.ACCEL_BVH])
+def test_builtin_raw_frames_bitexact(size, accel, textures, oracle_builtin):
+    """every view mode, several frames, ragged and degenerate sizes, both intersect back ends"""
+    w, h = size
+    cam = ko.default_camera()
+    with make_renderer(w, h, textures, max_frames=0, accel=accel) as r:
+        for mode in (kl.MODE_Z, kl.MODE_AO, kl.MODE_PT):
+            for frame in (0, 5):
+                got = render_raw(r, mode, frame)
+                p = ko.default_params(width=w, height=h, mode=KO_MODE[mode], max_frames=0)
+                want = oracle_builtin.render_raw(cam, p, frame)
+                assert_bitexact(got, want, "%dx%d mode %d frame %d accel %d" % (w, h, mode, frame, accel))
+
+
+@pytest.mark.parametrize("size", [(64, 36), (160, 90)])
+def test_builtin_against_llvmpipe_goldens(size, textures):
+    w, h = size
+    g = golden("builtin_%dx%d.npz" % (w, h))
+    modes = {"z": kl.MODE_Z, "ao": kl.MODE_AO, "pt": kl.MODE_PT}
+    with make_renderer(w, h, textures, max_frames=0) as r:
+        for key in sorted(g.files):
+            name, f = key.split("_f")
+            if name == "ptwhite":
+                continue
+            got = render_raw(r, modes[name], int(f))[..., :3]
+            ref = g[key]
+            if name == "z":
+                assert_bitexact(got, ref, key)                  # ZDepth reproduces llvmpipe bit for bit
+            elif name == "ao":
+                assert frac_within_rel(got, ref) >= 0.999, key  # 1e-4 relative, outlier budget 0.1 %
+            else:
+                assert frac_within_rel(got, ref) >= 0.99 and mae_clamped(got, ref) <= 5e-4, key
+    with make_renderer(w, h, None, max_frames=0) as r:          # 1x1 white textures
+        for f in (0, 5):
+            got = render_raw(r, kl.MODE_PT, f)[..., :3]
+            assert frac_within_rel(got, g["ptwhite_f%d" % f]) >= 0.999
+
+
+def test_config1_16spp(textures, oracle_builtin):
+    """BASELINE config 1: 640x360, 16 spp, path traced, 32-bounce cap, running mean"""
+    with make_renderer(640, 360, textures) as r:
+        r.set_mode(kl.MODE_PT)
+        r.render_frames(16)
+        assert r.frame == 16
+        acc = r.read_accum()
+        cn = r.counters()
+    p = ko.default_params(width=640, height=360, mode=ko.MODE_PT, max_frames=30)
+    ocn = ko.Counters()
+    want = ko.render_mean(oracle_builtin, ko.default_camera(), p, 16, counters=ocn)
+    assert_bitexact(acc, want, "config 1 mean")
+    assert cn.paths == 640 * 360 * 16 and cn.rays == ocn.rays      # same ray count as the CPU walk
+    ref = golden("config1_pt_640x360_16spp.npz")["acc"]
+    assert mae_clamped(acc[..., :3], ref) <= 1e-4                  # stated PT bound vs the reference shader
+
+
+@pytest.mark.parametrize("mode,name,budget", [(kl.MODE_Z, "z", 0.9999), (kl.MODE_AO, "ao", 0.99)])
+def test_config2_1080p(mode, name, budget, textures, oracle_builtin):
+    """BASELINE config 2: 1920x1080, frame 0, ZDepth and AO on one GPU"""
+    with make_renderer(1920, 1080, textures, max_frames=0) as r:
+        got = render_raw(r, mode, 0)
+    p = ko.default_params(width=1920, height=1080, mode=KO_MODE[mode], max_frames=0)
+    want = oracle_builtin.render_raw(ko.default_camera(), p, 0)
+    assert_bitexact(got, want, "config 2 " + name)
+    g = golden("config2_1920x1080_f0.npz")
+    assert frac_within_rel(got[3::8, :, 0], g[name + "_rows"]) >= budget
+    assert abs(got[..., 0].astype(np.float64).mean() - float(g[name + "_mean"])) <= 1e-6
+
+
+def test_batching_and_compaction_do_not_change_results(textures):
+    """frames in flight, fused vs separate compaction, brute vs BVH: identical accumulation"""
+    ref = None
+    for fif, fused, accel in ((1, 1, kl.ACCEL_BRUTE), (3, 1, kl.ACCEL_BRUTE), (16, 1, kl.ACCEL_BVH), (4, 0, kl.ACCEL_BRUTE), (5, 0, kl.ACCEL_BVH)):
+        with make_renderer(96, 54, textures, frames_in_flight=fif, fused_compaction=fused, accel=accel) as r:
+            r.render_frames(7)
+            r.render_frames(3)          # continues at frame 7
+            acc = r.read_accum()
+            raw = r.read_raw()
+        if ref is None:
+            ref = (acc, raw)
+        else:
+            assert_bitexact(acc, ref[0], "acc fif=%d fused=%d" % (fif, fused))
+            assert_bitexact(raw, ref[1], "raw fif=%d fused=%d" % (fif, fused))
+
+
+def test_samples_freeze_and_bounce_cap(textures, oracle_builtin):
+    cam = ko.default_camera()
+    with make_renderer(64, 36, textures, max_frames=4, frames_in_flight=3) as r:
+        r.render_frames(6)
+        acc = r.read_accum()
+    p = ko.default_params(width=64, height=36, mode=ko.MODE_PT, max_frames=4)
+    assert_bitexact(acc, ko.render_mean(oracle_builtin, cam, p, 6), "SAMPLES freeze")
+    assert mae_clamped(acc[..., :3], golden("pt_64x36_freeze4_6frames.npz")["acc"]) <= 1e-4
+    with make_renderer(160, 90, textures, max_bounces=8) as r:
+        r.render_frames(4)
+        acc = r.read_accum()
+    p = ko.default_params(width=160, height=90, mode=ko.MODE_PT, max_frames=30, max_bounces=8)
+    assert_bitexact(acc, ko.render_mean(oracle_builtin, cam, p, 4), "8-bounce cap")
+    assert mae_clamped(acc[..., :3], golden("pt_160x90_4spp_8bounce.npz")["acc"]) <= 1e-4
+
+
+def test_reset_rules(textures):
+    """mode/camera changes zero the frame counter (GLSL_Renderer.cpp:141-143,247-273); resize too (:72)"""
+    with make_renderer(32, 18, textures) as r:
+        r.render_frames(3)
+        assert r.frame == 3
+        r.set_mode(kl.MODE_Z)
+        assert r.frame == 0
+        r.render_frames(2)
+        z = r.read_accum()
+        assert_bitexact(z, r.read_raw(), "ZDepth mean of identical frames")
+        cam = kl.default_camera()
+        cam.pos[0] = 0.5
+        r.set_camera(cam)
+        assert r.frame == 0
+        r.render_frames(1)
+        assert not np.array_equal(r.read_accum(), z)
+        r.resize(40, 20)
+        assert r.frame == 0
+        r.render_frames(1)
+        assert r.read_accum().shape == (20, 40, 4)
+        r.recompile()
+        assert r.frame == 0
+
+
+def test_other_camera_and_params(textures, oracle_builtin):
+    cam = ko.default_camera()
+    cam.pos[:] = (1.2, 1.7, 3.0)
+    d = np.array([-0.3, -0.15, -1.0]); d /= np.linalg.norm(d)
+    cam.front[:] = [float(np.float32(v)) for v in d]
+    cam.focal, cam.sensor = 0.035, 0.03
+    kcam = kl.Camera.from_buffer_copy(bytes(cam))
+    for mode in (kl.MODE_Z, kl.MODE_AO, kl.MODE_PT):
+        with make_renderer(120, 80, textures, max_frames=0, ao_length=0.5, hdri_strength=1.5, eps=0.002, max_dist=40.0) as r:
+            r.set_camera(kcam)
+            got = render_raw(r, mode, 3)
+        p = ko.default_params(width=120, height=80, mode=KO_MODE[mode], max_frames=0, ao_length=0.5,
+                              hdri_strength=1.5, eps=0.002, max_dist=40.0)
+        assert_bitexact(got, oracle_builtin.render_raw(cam, p, 3), "camera/params mode %d" % mode)
+
+
+def test_resolve_matches_present_pass(textures):
+    with make_renderer(64, 36, textures) as r:
+        r.render_frames(2)
+        acc = r.read_accum()
+        for tm, otm in ((kl.TONEMAP_CLAMP, ko.TONEMAP_CLAMP), (kl.TONEMAP_ACES, ko.TONEMAP_ACES)):
+            assert np.array_equal(r.resolve(tm), ko.resolve(acc, otm))
+
+
+def test_error_behaviour():
+    with kl.Renderer(8, 8) as r:
+        with pytest.raises(kl.KlError, match="invalid state"):
+            r.render_frames(1)                       # no scene yet
+        with pytest.raises(kl.KlError):
+            r.set_mode(3)
+        with pytest.raises(kl.KlError):
+            r.update_params(max_bounces=0)
+        with pytest.raises(kl.KlError):
+            r.update_params(max_bounces=5000)
+        m = np.zeros(1, dtype=kl.material_dtype)
+        s = np.zeros(1, dtype=kl.sphere_dtype); s["material"] = 3
+        with pytest.raises(kl.KlError, match="out of range"):
+            r.upload_scene(spheres=s, materials=m)
+        with pytest.raises(kl.KlError):
+            r.upload_texture(kl.TEX_HDRI, np.zeros((2, 2, 2), dtype=np.uint8))
+        r.load_builtin_scene()
+        with pytest.raises(kl.KlError, match="nothing rendered"):
+            r.read_accum()
+        r.render_frames(0)                            # empty request is a no-op
+        assert r.frame == 0
+    with pytest.raises(kl.KlError):
+        kl.Renderer(8, 8, device=99)

@@ -1,0 +1,184 @@
+"""GPU suite: uploaded scenes (spheres + quads + triangles), the SAH BVH, partitioning.
+
+Triangles, the BVH and scene upload have no counterpart in the reference shader, so they are
+pinned by self-consistency: BVH traversal == flat loop == the CPU oracle (brute force and its
+own, differently shaped, median-split tree), bit for bit.
+"""
+import numpy as np
+import pytest
+
+import klrender as kl
+import kloracle as ko
+from test_gpu_parity import assert_bitexact, KO_MODE
+
+pytestmark = pytest.mark.gpu
+
+
+def random_rays(n, seed, box=((-2.6, 0.0, -15.0), (2.6, 3.0, 5.0))):
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array(box[0]), np.array(box[1])
+    o = (lo + (hi - lo) * rng.random((n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return o, d
+
+
+def oracle_trace(scene, o, d, use_bvh):
+    p = ko.default_params(use_bvh=use_bvh)
+    t = np.empty(len(o), dtype=np.float32)
+    prim = np.empty(len(o), dtype=np.int64)
+    uv = np.empty((len(o), 2), dtype=np.float32)
+    for i in range(len(o)):
+        prim[i], t[i], uv[i] = scene.trace(p, o[i], d[i])
+    return t, prim, uv
+
+
+@pytest.fixture(scope="module")
+def small_scene():
+    return kl.synth_scene(blobs=24, tris_per_blob=160, analytic_spheres=40, seed=3)
+
+
+def test_bvh_guarantees(small_scene):
+    s, q, t, m = small_scene
+    with kl.Renderer(8, 8) as r:
+        r.upload_scene(s, q, t, m)
+        st = r.bvh_stats()
+    assert (st.spheres, st.quads, st.tris) == (len(s), len(q), len(t))
+    assert st.max_depth <= 32 and 1 <= st.max_leaf_size <= 8
+    assert st.leaves <= len(s) + len(q) + len(t) and st.nodes == st.leaves - 1
+    assert st.node_bytes == st.nodes * 64
+
+
+def test_bvh_equals_flat_loop_equals_oracle(small_scene):
+    s, q, t, m = small_scene
+    o, d = random_rays(3000, 11)
+    # rays that start on geometry and axis-parallel rays stress the slab test
+    o[:50] = t["v0"][:50]
+    d[50:60] = np.eye(3, dtype=np.float32)[np.arange(10) % 3]
+    d[60:70] = -np.eye(3, dtype=np.float32)[np.arange(10) % 3]
+    d[70] = (np.nan, 0, 1)                                   # a NaN ray hits nothing
+    with kl.Renderer(8, 8) as r:
+        r.upload_scene(s, q, t, m)
+        r.update_params(accel=kl.ACCEL_BVH)
+        tb, pb, ub = r.trace_rays(o, d)
+        r.update_params(accel=kl.ACCEL_BRUTE)
+        tf, pf, uf = r.trace_rays(o, d)
+        r.update_params(accel=kl.ACCEL_BVH, collect_stats=1)
+        ts, ps, us = r.trace_rays(o, d)
+        cn = r.counters()
+    assert np.array_equal(pb, pf) and np.array_equal(ps, pf)
+    assert_bitexact(tb, tf, "t bvh vs flat")
+    assert_bitexact(ub, uf, "uv bvh vs flat")
+    assert_bitexact(ts, tf, "t bvh(stats) vs flat")
+    assert pf[70] == kl.MISS and (pf != kl.MISS).mean() > 0.9      # closed room: nearly every ray hits
+    assert cn.nodes > 0 and cn.tri_tests > 0 and 0 < cn.lane_steps_active <= cn.lane_steps_total
+    sc = ko.Scene(s, q, t, m)
+    for use_bvh in (0, 1):
+        to, po, uo = oracle_trace(sc, o[:600], d[:600], use_bvh)
+        assert np.array_equal(np.where(po < 0, kl.MISS, po).astype(np.uint32), pf[:600])
+        assert_bitexact(to, tf[:600], "t vs oracle")
+        assert_bitexact(uo, uf[:600], "uv vs oracle")
+
+
+@pytest.mark.parametrize("mode", [kl.MODE_Z, kl.MODE_AO, kl.MODE_PT])
+def test_synthetic_scene_render_bitexact(mode, small_scene, textures):
+    s, q, t, m = small_scene
+    sc = ko.Scene(s, q, t, m)
+    sc.set_texture(ko.TEX_HDRI, textures["hdri"]); sc.set_texture(ko.TEX_ALBEDO, textures["albedo"])
+    w, h = 128, 72
+    with kl.Renderer(w, h) as r:
+        r.upload_scene(s, q, t, m)
+        r.upload_texture(kl.TEX_HDRI, textures["hdri"]); r.upload_texture(kl.TEX_ALBEDO, textures["albedo"])
+        r.update_params(max_bounces=8, max_frames=0, accel=kl.ACCEL_BVH)
+        r.set_mode(mode)
+        r.render_frames(3)
+        acc = r.read_accum()
+    p = ko.default_params(width=w, height=h, mode=KO_MODE[mode], max_frames=0, max_bounces=8, use_bvh=1)
+    want = ko.render_mean(sc, ko.default_camera(), p, 3)
+    assert_bitexact(acc, want, "synthetic scene mode %d" % mode)
+    assert np.isfinite(acc).all() and acc[..., :3].max() > 0
+
+
+def test_million_triangle_scene_low_res(textures):
+    """BASELINE config 3's scene (1000 blobs x 1000 triangles) at a size the oracle finishes in seconds"""
+    s, q, t, m = kl.synth_scene(blobs=1000, tris_per_blob=1000, seed=1)
+    assert len(t) == 1_000_000
+    w, h = 96, 54
+    with kl.Renderer(w, h) as r:
+        r.upload_scene(s, q, t, m)
+        st = r.bvh_stats()
+        assert st.max_depth <= 32 and st.tris == 1_000_000
+        r.upload_texture(kl.TEX_HDRI, textures["hdri"]); r.upload_texture(kl.TEX_ALBEDO, textures["albedo"])
+        r.update_params(max_bounces=8, max_frames=0)
+        r.render_frames(2)
+        acc = r.read_accum()
+        o, d = random_rays(2048, 5)
+        tb, pb, ub = r.trace_rays(o, d)
+        r.update_params(accel=kl.ACCEL_BRUTE)                 # 2048 rays x 1M triangles through the flat loop
+        tf, pf, uf = r.trace_rays(o, d)
+    assert np.array_equal(pb, pf)
+    assert_bitexact(tb, tf, "1M tris: bvh vs flat t")
+    sc = ko.Scene(s, q, t, m)
+    sc.set_texture(ko.TEX_HDRI, textures["hdri"]); sc.set_texture(ko.TEX_ALBEDO, textures["albedo"])
+    p = ko.default_params(width=w, height=h, mode=ko.MODE_PT, max_frames=0, max_bounces=8, use_bvh=1)
+    assert_bitexact(acc, ko.render_mean(sc, ko.default_camera(), p, 2), "1M-triangle scene")
+
+
+@pytest.mark.parametrize("world,band_rows,size", [(2, 8, (96, 54)), (3, 5, (50, 33)), (8, 4, (64, 36)), (4, 16, (40, 10))])
+def test_row_band_shards_stitch_to_the_full_image(world, band_rows, size, small_scene, textures):
+    """image-tile partition: every rank renders its row bands with true global pixel coordinates;
+    stitched together the result is bit-identical to the one-GPU render (ragged last band included)"""
+    s, q, t, m = small_scene
+    w, h = size
+
+    def setup(r):
+        r.upload_scene(s, q, t, m)
+        r.upload_texture(kl.TEX_HDRI, textures["hdri"])
+        r.update_params(max_bounces=6, frames_in_flight=2)
+
+    with kl.Renderer(w, h) as r:
+        setup(r)
+        r.render_frames(3)
+        full = r.read_accum()
+    out = np.zeros_like(full)
+    seen = np.zeros(h, dtype=int)
+    for rank in range(world):
+        with kl.Renderer(w, h) as r:
+            setup(r)
+            r.set_shard(rank, world, band_rows)
+            rows = [y for y in range(h) if (y // band_rows) % world == rank]
+            assert r.local_rows == len(rows)
+            if not rows:
+                r.render_frames(3)        # a rank without rows is a no-op, not an error
+                continue
+            r.render_frames(3)
+            out[rows] = r.read_accum()
+            seen[rows] += 1
+    assert np.all(seen == 1)
+    assert_bitexact(out, full, "stitched shards")
+
+
+def test_sample_range_split_sums_to_the_mean(small_scene, textures):
+    """sample-range partition: disjoint frame ranges accumulated as sums, then added and divided"""
+    s, q, t, m = small_scene
+    w, h, n = 80, 45, 12
+
+    def setup(r):
+        r.upload_scene(s, q, t, m)
+        r.upload_texture(kl.TEX_HDRI, textures["hdri"])
+        r.update_params(max_bounces=6, max_frames=0)
+
+    with kl.Renderer(w, h) as r:
+        setup(r)
+        r.render_frames(n)
+        mean = r.read_accum()
+    total = np.zeros_like(mean, dtype=np.float64)
+    for g in range(3):
+        with kl.Renderer(w, h) as r:
+            setup(r)
+            r.set_accum_mode(kl.ACCUM_SUM)
+            r.render_frames(n // 3, first_frame=g * (n // 3))
+            total += r.read_accum()
+    got = (total[..., :3] / n).astype(np.float32)
+    # only fp32 re-association separates the two orders of summation
+    assert np.allclose(got, mean[..., :3], rtol=2e-5, atol=1e-6)
