@@ -26,6 +26,7 @@ constexpr uint32_t KL_MAX_DIM = 32768;
 constexpr uint32_t KL_MAX_FRAMES_IN_FLIGHT = 64;
 constexpr uint32_t KL_BRUTE_AUTO_LIMIT = 64;      // KL_ACCEL_AUTO uses the flat loop up to this many primitives
 constexpr size_t KL_MAX_PENDING_EVENTS = 8192;
+constexpr uint32_t KL_QUEUE_SEGMENTS = 64;        // independent sub-queues, each with its own tail/head counter
 
 struct EventPair { hipEvent_t a, b; int kind; };   // kind 0 = intersect launch, 1 = whole render call
 
@@ -60,11 +61,11 @@ struct kl_ctx {
     uint32_t n_prims = 0;
     SceneDev sc;
     kl_bvh_stats bvh_stats;
-    DevBuf<float4> d_nodes, d_sph, d_quad, d_tri, d_tri_shade, d_mats;
-    DevBuf<uint32_t> d_sph_id, d_quad_id, d_sph_mat, d_quad_mat;
+    DevBuf<float4> d_nodes, d_sph, d_quad, d_tri, d_tri_uv, d_mats;
     DevBuf<uchar4> d_tex[2];
     // wavefront state
     uint32_t slots = 0;               // frames in flight the buffers are sized for
+    uint32_t segcap = 0;              // entries per queue segment
     DevBuf<float4> d_od[2], d_tp[2], d_hits, d_raw, d_acc, d_last_raw;
     DevBuf<float2> d_d2[2];
     DevBuf<uint32_t> d_qctl;          // count[0..B], head[0..B]
@@ -115,12 +116,15 @@ kl_status ensure_buffers(kl_ctx *c) {
     KL_HIP(c, hipSetDevice(c->device));
     const uint32_t slots = choose_slots(c);
     const size_t cap = (size_t)slots * c->npl;
-    if (cap >= (1ull << 32)) return fail(c, KL_E_LIMIT, "frames_in_flight x pixels exceeds 2^32 paths");
+    if (cap >= (1ull << 31)) return fail(c, KL_E_LIMIT, "frames_in_flight x pixels exceeds 2^31 paths");
     c->slots = slots;
+    const size_t groups = (cap + 63) / 64;
+    c->segcap = (uint32_t)((groups + KL_QUEUE_SEGMENTS - 1) / KL_QUEUE_SEGMENTS * 64);
+    const size_t qcap = (size_t)c->segcap * KL_QUEUE_SEGMENTS;
     for (int k = 0; k < 2; k++) {
-        KL_HIP(c, c->d_od[k].alloc(cap)); KL_HIP(c, c->d_d2[k].alloc(cap)); KL_HIP(c, c->d_tp[k].alloc(cap));
+        KL_HIP(c, c->d_od[k].alloc(qcap)); KL_HIP(c, c->d_d2[k].alloc(qcap)); KL_HIP(c, c->d_tp[k].alloc(qcap));
     }
-    KL_HIP(c, c->d_hits.alloc(cap));
+    KL_HIP(c, c->d_hits.alloc(qcap));
     KL_HIP(c, c->d_raw.alloc(cap));
     bool fresh = c->d_acc.n != c->npl;
     KL_HIP(c, c->d_acc.alloc(c->npl));
@@ -129,7 +133,7 @@ kl_status ensure_buffers(kl_ctx *c) {
         KL_HIP(c, hipMemsetAsync(c->d_acc.p, 0, c->npl * sizeof(float4), c->stream));
         KL_HIP(c, hipMemsetAsync(c->d_last_raw.p, 0, c->npl * sizeof(float4), c->stream));
     }
-    KL_HIP(c, c->d_qctl.alloc(2 * ((size_t)c->params.max_bounces + 2)));
+    KL_HIP(c, c->d_qctl.alloc(2 * ((size_t)c->params.max_bounces + 2) * KL_QUEUE_SEGMENTS));
     if (!c->d_counters.p) {
         KL_HIP(c, c->d_counters.alloc(1));
         KL_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream));
@@ -178,6 +182,7 @@ FrameDev make_frame(const kl_ctx *c, uint32_t first_frame, uint32_t nslots) {
     f.max_bounces = c->params.max_bounces; f.max_frames = c->params.max_frames;
     f.eps = c->params.eps; f.max_dist = c->params.max_dist;
     f.ao_length = c->params.ao_length; f.hdri_strength = c->params.hdri_strength;
+    f.nseg = KL_QUEUE_SEGMENTS; f.segcap = c->segcap;
     return f;
 }
 
@@ -205,19 +210,21 @@ kl_status timed_intersect(kl_ctx *c, const FrameDev &f, RayQueue q, uint32_t *co
 kl_status render_batch(kl_ctx *c, uint32_t first, uint32_t nslots, bool camera_change) {
     FrameDev f = make_frame(c, first, nslots);
     const uint32_t B = c->params.max_bounces;
-    uint32_t *count = c->d_qctl.p, *head = c->d_qctl.p + (B + 2);
+    // count[b] / head[b]: one word per queue segment and bounce
+    const uint32_t S = KL_QUEUE_SEGMENTS;
+    uint32_t *count = c->d_qctl.p, *head = c->d_qctl.p + (size_t)(B + 2) * S;
     const uint32_t max_rays = nslots * c->npl;
     RayQueue q[2] = { {c->d_od[0].p, c->d_d2[0].p, c->d_tp[0].p}, {c->d_od[1].p, c->d_d2[1].p, c->d_tp[1].p} };
     const bool fused = c->params.fused_compaction != 0;
     KL_HIP(c, hipMemsetAsync(c->d_qctl.p, 0, c->d_qctl.n * sizeof(uint32_t), c->stream));
-    launch_generate(c->stream, c->lc, f, q[0], &count[0]);
+    launch_generate(c->stream, c->lc, f, q[0], count);
     const uint32_t levels = c->mode == KL_MODE_PT ? B : (c->mode == KL_MODE_AO ? 2u : 1u);
     for (uint32_t b = 0; b < levels; b++) {
         RayQueue qi = q[b & 1u], qo = q[(b + 1u) & 1u];
-        kl_status s = timed_intersect(c, f, qi, &count[b], &head[b], max_rays);
+        kl_status s = timed_intersect(c, f, qi, count + (size_t)b * S, head + (size_t)b * S, max_rays);
         if (s != KL_OK) return s;
-        launch_shade(c->stream, c->lc, c->sc, f, qi, c->d_hits.p, &count[b], qo, &count[b + 1], c->d_raw.p, b, fused, max_rays);
-        if (!fused && b + 1 < levels) launch_compact(c->stream, c->lc, qi, &count[b], qo, &count[b + 1], max_rays);
+        launch_shade(c->stream, c->lc, c->sc, f, qi, c->d_hits.p, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, c->d_raw.p, b, fused, max_rays);
+        if (!fused && b + 1 < levels) launch_compact(c->stream, c->lc, f, qi, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, max_rays);
     }
     launch_accumulate(c->stream, c->lc, f, c->d_raw.p, c->d_acc.p, c->d_last_raw.p, camera_change, c->accum_mode);
     KL_HIP(c, hipGetLastError());
@@ -301,8 +308,8 @@ kl_status kl_destroy(kl_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (const EventPair &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
-    c->d_nodes.release(); c->d_sph.release(); c->d_quad.release(); c->d_tri.release(); c->d_tri_shade.release();
-    c->d_mats.release(); c->d_sph_id.release(); c->d_quad_id.release(); c->d_sph_mat.release(); c->d_quad_mat.release();
+    c->d_nodes.release(); c->d_sph.release(); c->d_quad.release(); c->d_tri.release(); c->d_tri_uv.release();
+    c->d_mats.release();
     for (int k = 0; k < 2; k++) { c->d_tex[k].release(); c->d_od[k].release(); c->d_d2[k].release(); c->d_tp[k].release(); }
     c->d_hits.release(); c->d_raw.release(); c->d_acc.release(); c->d_last_raw.release();
     c->d_qctl.release(); c->d_counters.release(); c->d_resolve.release();
@@ -383,32 +390,33 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     HostBVH bvh;
     unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     build_bvh(s, ns, q, nq, t, nt, bvh, threads);
-    // leaf-ordered geometry and shading arrays
-    std::vector<float4> sph(ns), quad((size_t)nq * 3), tri((size_t)nt * 3), tsh((size_t)nt * 2), mats((size_t)nm * 2);
-    std::vector<uint32_t> sph_id(ns), quad_id(nq), sph_mat(ns), quad_mat(nq);
+    // leaf-ordered 64-byte primitive records (layout: kl_types.hpp)
+    auto bits = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+    std::vector<float4> sph((size_t)ns * 4), quad((size_t)nq * 4), tri((size_t)nt * 4), tuv((size_t)nt * 2), mats((size_t)nm * 2);
     for (uint32_t k = 0; k < ns; k++) {
         const kl_sphere &x = s[bvh.sph_order[k]];
-        sph[k] = make_float4(x.center[0], x.center[1], x.center[2], x.radius);
-        sph_id[k] = bvh.sph_order[k]; sph_mat[k] = x.material;
+        sph[4 * (size_t)k] = make_float4(x.center[0], x.center[1], x.center[2], x.radius);
+        sph[4 * (size_t)k + 1] = make_float4(bits(bvh.sph_order[k]), bits(x.material), 0.0f, 0.0f);
+        sph[4 * (size_t)k + 2] = sph[4 * (size_t)k + 3] = make_float4(0, 0, 0, 0);
     }
     for (uint32_t k = 0; k < nq; k++) {
         const kl_quad &x = q[bvh.quad_order[k]];
-        quad[3 * (size_t)k] = make_float4(x.v0[0], x.v0[1], x.v0[2], x.v1[0]);
-        quad[3 * (size_t)k + 1] = make_float4(x.v1[1], x.v1[2], x.v2[0], x.v2[1]);
-        quad[3 * (size_t)k + 2] = make_float4(x.v2[2], x.v3[0], x.v3[1], x.v3[2]);
-        quad_id[k] = ns + bvh.quad_order[k]; quad_mat[k] = x.material;
+        quad[4 * (size_t)k] = make_float4(x.v0[0], x.v0[1], x.v0[2], x.v1[0]);
+        quad[4 * (size_t)k + 1] = make_float4(x.v1[1], x.v1[2], x.v2[0], x.v2[1]);
+        quad[4 * (size_t)k + 2] = make_float4(x.v2[2], x.v3[0], x.v3[1], x.v3[2]);
+        quad[4 * (size_t)k + 3] = make_float4(bits(ns + bvh.quad_order[k]), bits(x.material), 0.0f, 0.0f);
     }
     for (uint32_t k = 0; k < nt; k++) {
         const kl_tri &x = t[bvh.tri_order[k]];
         v3 v0 = V(x.v0[0], x.v0[1], x.v0[2]);
         v3 e1 = V(x.v1[0], x.v1[1], x.v1[2]) - v0, e2 = V(x.v2[0], x.v2[1], x.v2[2]) - v0;
-        uint32_t id = ns + nq + bvh.tri_order[k];
-        float idf, matf; std::memcpy(&idf, &id, 4); std::memcpy(&matf, &x.material, 4);
-        tri[3 * (size_t)k] = make_float4(v0.x, v0.y, v0.z, e1.x);
-        tri[3 * (size_t)k + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-        tri[3 * (size_t)k + 2] = make_float4(e2.z, idf, 0.0f, 0.0f);
-        tsh[2 * (size_t)k] = make_float4(x.uv0[0], x.uv0[1], x.uv1[0], x.uv1[1]);
-        tsh[2 * (size_t)k + 1] = make_float4(x.uv2[0], x.uv2[1], matf, 0.0f);
+        v3 nor = normalize(cross(e1, e2));       // the flat shading normal, in the arithmetic the shade stage would use
+        tri[4 * (size_t)k] = make_float4(v0.x, v0.y, v0.z, e1.x);
+        tri[4 * (size_t)k + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+        tri[4 * (size_t)k + 2] = make_float4(e2.z, bits(ns + nq + bvh.tri_order[k]), bits(x.material), 0.0f);
+        tri[4 * (size_t)k + 3] = make_float4(nor.x, nor.y, nor.z, 0.0f);
+        tuv[2 * (size_t)k] = make_float4(x.uv0[0], x.uv0[1], x.uv1[0], x.uv1[1]);
+        tuv[2 * (size_t)k + 1] = make_float4(x.uv2[0], x.uv2[1], 0.0f, 0.0f);
     }
     for (uint32_t k = 0; k < nm; k++) {
         float tf; std::memcpy(&tf, &m[k].type, 4);
@@ -420,22 +428,16 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     if ((st = upload(c, c->d_sph, sph.data(), sph.size())) != KL_OK) return st;
     if ((st = upload(c, c->d_quad, quad.data(), quad.size())) != KL_OK) return st;
     if ((st = upload(c, c->d_tri, tri.data(), tri.size())) != KL_OK) return st;
-    if ((st = upload(c, c->d_tri_shade, tsh.data(), tsh.size())) != KL_OK) return st;
+    if ((st = upload(c, c->d_tri_uv, tuv.data(), tuv.size())) != KL_OK) return st;
     if ((st = upload(c, c->d_mats, mats.data(), mats.size())) != KL_OK) return st;
-    if ((st = upload(c, c->d_sph_id, sph_id.data(), sph_id.size())) != KL_OK) return st;
-    if ((st = upload(c, c->d_quad_id, quad_id.data(), quad_id.size())) != KL_OK) return st;
-    if ((st = upload(c, c->d_sph_mat, sph_mat.data(), sph_mat.size())) != KL_OK) return st;
-    if ((st = upload(c, c->d_quad_mat, quad_mat.data(), quad_mat.size())) != KL_OK) return st;
     KL_HIP(c, hipStreamSynchronize(c->stream));     // the host vectors go out of scope below
     c->sc.nodes = c->d_nodes.p; c->sc.root = bvh.root; c->sc.n_nodes = bvh.stats.nodes;
     c->sc.sph = c->d_sph.p; c->sc.quad = c->d_quad.p; c->sc.tri = c->d_tri.p;
-    c->sc.sph_id = c->d_sph_id.p; c->sc.quad_id = c->d_quad_id.p;
-    c->sc.sph_mat = c->d_sph_mat.p; c->sc.quad_mat = c->d_quad_mat.p;
-    c->sc.tri_shade = c->d_tri_shade.p; c->sc.mats = c->d_mats.p;
+    c->sc.tri_uv = c->d_tri_uv.p; c->sc.mats = c->d_mats.p;
     c->sc.ns = ns; c->sc.nq = nq; c->sc.nt = nt; c->sc.nm = nm;
     c->n_prims = ns + nq + nt;
     c->bvh_stats = bvh.stats;
-    c->bvh_stats.prim_bytes = (uint64_t)ns * 16 + (uint64_t)nq * 48 + (uint64_t)nt * 48;
+    c->bvh_stats.prim_bytes = ((uint64_t)ns + nq + nt) * 64;
     c->have_scene = true;
     return kl_reset(c);
 }
@@ -582,6 +584,7 @@ kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, f
     KL_HIP(c, hipMemcpyAsync(b_d2.p, d2.data(), n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
     KL_HIP(c, hipMemcpyAsync(b_ctl.p, ctl, sizeof ctl, hipMemcpyHostToDevice, c->stream));
     FrameDev f = make_frame(c, 0, 1);
+    f.nseg = 1; f.segcap = n;                       // caller rays form one segment
     RayQueue q = { b_od.p, b_d2.p, nullptr };
     launch_intersect(c->stream, c->lc, c->sc, f, q, b_hits.p, &b_ctl.p[0], &b_ctl.p[1], c->d_counters.p, use_bvh(c),
                      c->params.collect_stats != 0, n);

@@ -59,11 +59,12 @@ __device__ __forceinline__ bool sphere_intersect(v3 o, v3 d, float4 s, float eps
 }
 // RF:218-269 inverse-bilinear patch; uv out = (v, 1-u). May report "hit" with a NaN t,
 // which the caller's comparison rejects exactly as RF:316 does.
-__device__ __forceinline__ bool quad_intersect(v3 o, v3 d, v3 v0, v3 v1, v3 v2, v3 v3_, float &t_out, float &uo, float &vo) {
+__device__ __forceinline__ bool quad_intersect(v3 o, v3 d, v3 v0, v3 v1, v3 v2, v3 v3_, float best, float &t_out, float &uo, float &vo) {
     v3 a = v1 - v0, b = v3_ - v0, c = v2 - v0, p = o - v0;
     v3 nor = cross(a, b);
     float t = -dot(p, nor) / dot(d, nor);
     if (t < 0.0f) return false;
+    if (!(t > 0.001f && t <= best)) return false;    // would fail RF:316 whatever (u, v) turn out to be
     v3 pos = p + d * t;
     v3 mor = V(fabsf(nor.x), fabsf(nor.y), fabsf(nor.z));
     int id = (mor.x > mor.y && mor.x > mor.z) ? 0 : ((mor.y > mor.z) ? 1 : 2);
@@ -116,18 +117,19 @@ struct Hit { float t; uint32_t ref; float u, v; uint32_t id; };
 __device__ __forceinline__ void accept(Hit &h, float t, uint32_t ref, uint32_t id, float u, float v) {
     if (t > 0.001f && (t < h.t || (t == h.t && id < h.id))) { h.t = t; h.ref = ref; h.id = id; h.u = u; h.v = v; }
 }
-__device__ __forceinline__ void test_sphere(const SceneDev &sc, uint32_t i, v3 o, v3 d, float eps, Hit &h) {
+// primitive tests on the 64-byte records of kl_types.hpp
+__device__ __forceinline__ void test_sphere(float4 r0, float4 r1, uint32_t i, v3 o, v3 d, float eps, Hit &h) {
     float t;
-    if (sphere_intersect(o, d, sc.sph[i], eps, t)) accept(h, t, make_ref(PRIM_SPHERE, i), sc.sph_id[i], 0.0f, 0.0f);
+    if (sphere_intersect(o, d, r0, eps, t)) accept(h, t, make_ref(PRIM_SPHERE, i), __float_as_uint(r1.x), 0.0f, 0.0f);
 }
-__device__ __forceinline__ void test_quad(const SceneDev &sc, uint32_t i, v3 o, v3 d, Hit &h) {
-    float4 a = sc.quad[3 * i], b = sc.quad[3 * i + 1], c = sc.quad[3 * i + 2];
+__device__ __forceinline__ void test_quad(float4 a, float4 b, float4 c, float4 e, uint32_t i, v3 o, v3 d, Hit &h) {
+    // the plane distance is the first thing RF:225 computes; a candidate that cannot pass the
+    // acceptance test of RF:316 is dropped before the inverse-bilinear solve (same outcome)
     float t, u, v;
-    if (quad_intersect(o, d, V(a.x, a.y, a.z), V(a.w, b.x, b.y), V(b.z, b.w, c.x), V(c.y, c.z, c.w), t, u, v))
-        accept(h, t, make_ref(PRIM_QUAD, i), sc.quad_id[i], u, v);
+    if (quad_intersect(o, d, V(a.x, a.y, a.z), V(a.w, b.x, b.y), V(b.z, b.w, c.x), V(c.y, c.z, c.w), h.t, t, u, v))
+        accept(h, t, make_ref(PRIM_QUAD, i), __float_as_uint(e.x), u, v);
 }
-__device__ __forceinline__ void test_tri(const SceneDev &sc, uint32_t i, v3 o, v3 d, Hit &h) {
-    float4 a = sc.tri[3 * i], b = sc.tri[3 * i + 1], c = sc.tri[3 * i + 2];
+__device__ __forceinline__ void test_tri(float4 a, float4 b, float4 c, uint32_t i, v3 o, v3 d, Hit &h) {
     float t, u, v;
     if (tri_intersect(o, d, V(a.x, a.y, a.z), V(a.w, b.x, b.y), V(b.z, b.w, c.x), t, u, v))
         accept(h, t, make_ref(PRIM_TRI, i), __float_as_uint(c.y), u, v);
@@ -141,7 +143,15 @@ __device__ __forceinline__ bool ray_finite(v3 o, v3 d) {
 // RF:417-422 with the uv arithmetic of RF:428-429,436; one thread per (slot, pixel)
 __global__ __launch_bounds__(256) void k_generate(FrameDev f, RayQueue q, uint32_t *count0) {
     const uint32_t total = f.nslots * f.npl;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count0 = total;
+    const uint32_t groups = (total + 63u) >> 6;            // 64-path groups, dealt round-robin over the segments
+    if (blockIdx.x == 0) {
+        for (uint32_t s = threadIdx.x; s < f.nseg; s += blockDim.x) {
+            uint32_t ng = s < groups ? (groups - s + f.nseg - 1u) / f.nseg : 0u;
+            uint32_t n = ng * 64u;
+            if (ng && (groups - 1u) % f.nseg == s) n -= groups * 64u - total;   // the last group may be partial
+            count0[s] = n;
+        }
+    }
     const float rx = (float)f.width, ry = (float)f.height;
     const float m = fmaxf(rx, ry);
     const v3 pos = ldv(f.pos), pc = ldv(f.pc), pu = ldv(f.pu), pv = ldv(f.pv);
@@ -156,9 +166,11 @@ __global__ __launch_bounds__(256) void k_generate(FrameDev f, RayQueue q, uint32
             uy = (uy - 0.5f * psy) + (0.0f / 1.0f) * psy;
         }
         v3 d = normalize(pc + pu * ux + pv * uy - pos);
-        q.od[i] = make_float4(pos.x, pos.y, pos.z, d.x);
-        q.d2[i] = make_float2(d.y, d.z);
-        q.tp[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(i));
+        const uint32_t g = i >> 6;
+        const uint32_t dst = (g % f.nseg) * f.segcap + (g / f.nseg) * 64u + (i & 63u);
+        q.od[dst] = make_float4(pos.x, pos.y, pos.z, d.x);
+        q.d2[dst] = make_float2(d.y, d.z);
+        q.tp[dst] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(i));
     }
 }
 
@@ -166,17 +178,20 @@ __global__ __launch_bounds__(256) void k_generate(FrameDev f, RayQueue q, uint32
 // RF:294-328 for scenes of a few primitives: every lane walks the same primitive list, so the
 // geometry comes through uniform (scalar) loads and nothing but the ray and hit touch memory.
 __global__ __launch_bounds__(256) void k_intersect_brute(SceneDev sc, FrameDev f, RayQueue q, float4 *hits,
-                                                         const uint32_t *count_ptr, Counters *cn) {
-    const uint32_t count = *count_ptr;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(&cn->rays, (unsigned long long)count);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+                                                         const uint32_t *counts, Counters *cn) {
+    // block b works on segment b % nseg together with the other blocks of that residue
+    const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
+    const uint32_t count = counts[seg];
+    if (sub == 0 && threadIdx.x == 0 && count) atomicAdd(&cn->rays, (unsigned long long)count);
+    for (uint32_t r = sub * blockDim.x + threadIdx.x; r < count; r += nsub * blockDim.x) {
+        const uint32_t i = seg * f.segcap + r;
         float4 od = q.od[i]; float2 d2 = q.d2[i];
         v3 o = V(od.x, od.y, od.z), d = V(od.w, d2.x, d2.y);
         Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
         if (ray_finite(o, d)) {
-            for (uint32_t k = 0; k < sc.ns; k++) test_sphere(sc, k, o, d, f.eps, h);
-            for (uint32_t k = 0; k < sc.nq; k++) test_quad(sc, k, o, d, h);
-            for (uint32_t k = 0; k < sc.nt; k++) test_tri(sc, k, o, d, h);
+            for (uint32_t k = 0; k < sc.ns; k++) test_sphere(sc.sph[4 * k], sc.sph[4 * k + 1], k, o, d, f.eps, h);
+            for (uint32_t k = 0; k < sc.nq; k++) test_quad(sc.quad[4 * k], sc.quad[4 * k + 1], sc.quad[4 * k + 2], sc.quad[4 * k + 3], k, o, d, h);
+            for (uint32_t k = 0; k < sc.nt; k++) test_tri(sc.tri[4 * k], sc.tri[4 * k + 1], sc.tri[4 * k + 2], k, o, d, h);
         }
         hits[i] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
     }
@@ -189,13 +204,17 @@ constexpr uint32_t ISECT_REFILL = 40;        // refill idle lanes when fewer tha
 
 template <bool STATS>
 __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc, FrameDev f, RayQueue q, float4 *hits,
-                                                                   const uint32_t *count_ptr, uint32_t *head, Counters *cn) {
+                                                                   const uint32_t *counts, uint32_t *heads, Counters *cn) {
     // per-lane traversal stack: entry e of lane l of wave w at [w][e][l] -> consecutive lanes hit consecutive banks
     __shared__ int stack[ISECT_WAVES][BVH_MAX_DEPTH][64];
     const uint32_t lane = lane_id();
     int *st = &stack[threadIdx.x >> 6][0][lane];
-    const uint32_t count = *count_ptr;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(&cn->rays, (unsigned long long)count);
+    // this workgroup serves queue segment blockIdx % nseg; its waves pull ray chunks from that segment's head
+    const uint32_t seg = blockIdx.x % f.nseg;
+    const uint32_t count = counts[seg];
+    uint32_t *head = heads + seg;
+    const uint32_t seg_base = seg * f.segcap;
+    if (blockIdx.x < f.nseg && threadIdx.x == 0 && count) atomicAdd(&cn->rays, (unsigned long long)count);
 
     uint32_t cur = 0, end = 0;               // wave-uniform: rays [cur, end) reserved by this wave
     bool exhausted = false;                  // wave-uniform: the global counter has run past count
@@ -221,7 +240,7 @@ __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc,
             uint32_t take = min(avail, want);
             uint32_t r = mask_rank(idle);
             if (!active && r < take) {
-                ray = cur + r;
+                ray = seg_base + cur + r;
                 float4 od = q.od[ray]; float2 d2 = q.d2[ray];
                 o = V(od.x, od.y, od.z); d = V(od.w, d2.x, d2.y);
                 h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
@@ -232,8 +251,12 @@ __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc,
                 id = V(1.0f / sx, 1.0f / sy, 1.0f / sz);
                 nood = V(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
                 sp = 0;
-                node = ray_finite(o, d) ? sc.root : NODE_DONE;   // a NaN ray hits nothing (as in the flat loop)
+                node = sc.root;
                 active = true;
+                if (node == NODE_DONE || !ray_finite(o, d)) {    // empty scene, or a NaN ray: hits nothing
+                    hits[ray] = make_float4(h.t, __uint_as_float(REF_MISS), 0.0f, 0.0f);
+                    active = false;
+                }
             }
             cur += take;
         }
@@ -241,15 +264,19 @@ __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc,
         if (am == 0ull) { if (exhausted && cur == end) break; else continue; }
         const uint32_t thresh = (exhausted && cur == end) ? 1u : ISECT_REFILL;
 
-        // ---- traverse until too few lanes are busy
+        // ---- traverse until too few lanes are busy. Every iteration fetches ONE 64-byte record per
+        // lane (an inner node or one primitive of the current leaf) with a single group of loads, so a
+        // wave pays one memory latency per step whatever mix of nodes and primitives its lanes are on.
         do {
             if (active) {
-                if (node == NODE_DONE) {
-                    hits[ray] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
-                    active = false;
-                } else if (node >= 0) {
-                    const float4 *np = sc.nodes + 4u * (uint32_t)node;
-                    float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                const bool inner = node >= 0;
+                const uint32_t lv = (uint32_t)~node;
+                const uint32_t type = (lv >> 29) & 3u, start = lv & 0x3FFFFFFu;
+                const float4 *rec = inner ? sc.nodes + 4u * (uint32_t)node
+                                          : (type == PRIM_TRI ? sc.tri : (type == PRIM_SPHERE ? sc.sph : sc.quad)) + 4u * start;
+                const float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+                bool pop = false;
+                if (inner) {
                     if (STATS) s_nodes++;
                     float ax0 = fmaf(n0.x, id.x, nood.x), ax1 = fmaf(n0.w, id.x, nood.x);
                     float ay0 = fmaf(n0.y, id.y, nood.y), ay1 = fmaf(n1.x, id.y, nood.y);
@@ -270,23 +297,17 @@ __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc,
                         node = nearc;
                     } else if (hit0) node = c0;
                     else if (hit1) node = c1;
-                    else if (sp > 0) { sp--; node = st[sp * 64]; }
-                    else node = NODE_DONE;
+                    else pop = true;
                 } else {
-                    uint32_t lv = (uint32_t)~node;
-                    uint32_t start = lv & 0x3FFFFFFu, cnt = ((lv >> 26) & 7u) + 1u, type = (lv >> 29) & 3u;
-                    if (type == PRIM_TRI) {
-                        for (uint32_t k = 0; k < cnt; k++) test_tri(sc, start + k, o, d, h);
-                        if (STATS) s_tri += cnt;
-                    } else if (type == PRIM_SPHERE) {
-                        for (uint32_t k = 0; k < cnt; k++) test_sphere(sc, start + k, o, d, f.eps, h);
-                        if (STATS) s_sph += cnt;
-                    } else {
-                        for (uint32_t k = 0; k < cnt; k++) test_quad(sc, start + k, o, d, h);
-                        if (STATS) s_quad += cnt;
-                    }
+                    if (type == PRIM_TRI) { test_tri(n0, n1, n2, start, o, d, h); if (STATS) s_tri++; }
+                    else if (type == PRIM_SPHERE) { test_sphere(n0, n1, start, o, d, f.eps, h); if (STATS) s_sph++; }
+                    else { test_quad(n0, n1, n2, n3, start, o, d, h); if (STATS) s_quad++; }
+                    if ((lv >> 26) & 7u) node = ~(int)(lv + 1u - (1u << 26));   // next primitive of this leaf
+                    else pop = true;
+                }
+                if (pop) {
                     if (sp > 0) { sp--; node = st[sp * 64]; }
-                    else node = NODE_DONE;
+                    else { hits[ray] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v); active = false; }
                 }
             }
             am = __ballot(active);
@@ -315,30 +336,25 @@ __device__ __forceinline__ Surf surface(const SceneDev &sc, v3 o, v3 d, float t,
     Surf s;
     s.pos = o + d * t;                                             // RF:304,318
     uint32_t i = ref_index(ref), type = ref_type(ref);
+    const float4 *rec = (type == PRIM_TRI ? sc.tri : (type == PRIM_SPHERE ? sc.sph : sc.quad)) + 4u * i;
+    const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
     if (type == PRIM_SPHERE) {
-        float4 sp = sc.sph[i];
-        v3 c = V(sp.x, sp.y, sp.z);
-        s.n = normalize(s.pos - c);                                // RF:305
-        s.inside = length(o - c) <= sp.w;                          // RF:308
+        v3 ctr = V(a.x, a.y, a.z);
+        s.n = normalize(s.pos - ctr);                              // RF:305
+        s.inside = length(o - ctr) <= a.w;                         // RF:308
         if (s.inside) s.n = s.n * -1.0f;                           // RF:309
-        s.mat = sc.sph_mat[i]; s.u = 0.0f; s.v = 0.0f;
+        s.mat = __float_as_uint(b.y); s.u = 0.0f; s.v = 0.0f;
     } else if (type == PRIM_QUAD) {
-        float4 a = sc.quad[3 * i], b = sc.quad[3 * i + 1], c = sc.quad[3 * i + 2];
         v3 v1 = V(a.w, b.x, b.y), v2 = V(b.z, b.w, c.x), v3_ = V(c.y, c.z, c.w);
         v3 nor = normalize(cross(v2 - v1, v3_ - v1));              // RF:319
         s.n = dot(nor, d) < 0.0f ? nor : -nor;                     // faceforward, RF:320
-        s.inside = false; s.mat = sc.quad_mat[i]; s.u = hu; s.v = hv;
+        s.inside = false; s.mat = __float_as_uint(e.y); s.u = hu; s.v = hv;
     } else {
-        float4 a = sc.tri[3 * i], b = sc.tri[3 * i + 1], c = sc.tri[3 * i + 2];
-        v3 e1 = V(a.w, b.x, b.y), e2 = V(b.z, b.w, c.x);
-        v3 nor = normalize(cross(e1, e2));
+        v3 nor = V(e.x, e.y, e.z);                                 // normalize(cross(e1, e2)), stored at upload
         s.n = dot(nor, d) < 0.0f ? nor : -nor;
         s.inside = false;
-        float4 s0 = sc.tri_shade[2 * i], s1 = sc.tri_shade[2 * i + 1];
-        s.mat = __float_as_uint(s1.z);
-        float w = (1.0f - hu) - hv;
-        s.u = (s0.x * w + s0.z * hu) + s1.x * hv;
-        s.v = (s0.y * w + s0.w * hu) + s1.y * hv;
+        s.mat = __float_as_uint(c.z);
+        s.u = hu; s.v = hv;                                        // barycentrics; texture coordinates on demand
     }
     return s;
 }
@@ -399,14 +415,18 @@ constexpr uint32_t PATH_DEAD = 0xFFFFFFFFu;
 // pushed to qout (fused compaction) or written back in place for k_compact.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue qin, const float4 *hits,
-                                               const uint32_t *count_in, RayQueue qout, uint32_t *count_out,
+                                               const uint32_t *counts_in, RayQueue qout, uint32_t *counts_out,
                                                float4 *raw, uint32_t bounce, uint32_t fused) {
-    const uint32_t count = *count_in;
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // block b works on segment b % nseg; survivors stay in their segment
+    const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
+    const uint32_t count = counts_in[seg];
+    uint32_t *count_out = counts_out + seg;
+    const uint32_t seg_base = seg * f.segcap;
+    const uint32_t nwaves = (nsub * blockDim.x) >> 6;
+    const uint32_t wave = (sub * blockDim.x + threadIdx.x) >> 6;
     for (uint32_t base = wave * 64u; base < count; base += nwaves * 64u) {
-        const uint32_t i = base + lane_id();
-        const bool valid = i < count;
+        const uint32_t i = seg_base + base + lane_id();
+        const bool valid = base + lane_id() < count;
         bool alive = false;
         v3 o = V(0, 0, 0), d = V(0, 0, 0), thr = V(0, 0, 0);
         uint32_t path = PATH_DEAD;
@@ -444,7 +464,14 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
                     const v3 mcol = V(m0.y, m0.z, m0.w);
                     if (mtype == KL_DIFFUSE || mtype == KL_TEXTURED) {           // RF:365-378
                         if (mtype == KL_TEXTURED) {
-                            col = thr * tex_fetch(sc, KL_TEX_ALBEDO, s.u, s.v);
+                            float tu = s.u, tv = s.v;
+                            if (ref_type(ref) == PRIM_TRI) {
+                                float4 s0 = sc.tri_uv[2 * ref_index(ref)], s1 = sc.tri_uv[2 * ref_index(ref) + 1];
+                                float w = (1.0f - s.u) - s.v;
+                                tu = (s0.x * w + s0.z * s.u) + s1.x * s.v;
+                                tv = (s0.y * w + s0.w * s.u) + s1.y * s.v;
+                            }
+                            col = thr * tex_fetch(sc, KL_TEX_ALBEDO, tu, tv);
                         } else {
                             v3 tangent = normalize(cross(d, s.n));
                             v3 bitangent = normalize(cross(s.n, tangent));
@@ -483,7 +510,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
             alive = !done;
         }
         if (fused) {
-            uint32_t slot_out = wave_reserve(count_out, alive);
+            uint32_t slot_out = seg_base + wave_reserve(count_out, alive);
             if (alive) {
                 qout.od[slot_out] = make_float4(o.x, o.y, o.z, d.x);
                 qout.d2[slot_out] = make_float2(d.y, d.z);
@@ -499,16 +526,18 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
 
 // ------------------------------------------------------------------ compact
 // stream compaction of a shaded queue: ballot + popcount, one atomic per wave
-__global__ __launch_bounds__(256) void k_compact(RayQueue qin, const uint32_t *count_in, RayQueue qout, uint32_t *count_out) {
-    const uint32_t count = *count_in;
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__global__ __launch_bounds__(256) void k_compact(FrameDev f, RayQueue qin, const uint32_t *counts_in, RayQueue qout, uint32_t *counts_out) {
+    const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
+    const uint32_t count = counts_in[seg];
+    const uint32_t seg_base = seg * f.segcap;
+    const uint32_t nwaves = (nsub * blockDim.x) >> 6;
+    const uint32_t wave = (sub * blockDim.x + threadIdx.x) >> 6;
     for (uint32_t base = wave * 64u; base < count; base += nwaves * 64u) {
-        const uint32_t i = base + lane_id();
+        const uint32_t i = seg_base + base + lane_id();
         float4 tp = make_float4(0, 0, 0, 0);
         bool alive = false;
-        if (i < count) { tp = qin.tp[i]; alive = __float_as_uint(tp.w) != PATH_DEAD; }
-        uint32_t dst = wave_reserve(count_out, alive);
+        if (base + lane_id() < count) { tp = qin.tp[i]; alive = __float_as_uint(tp.w) != PATH_DEAD; }
+        uint32_t dst = seg_base + wave_reserve(counts_out + seg, alive);
         if (alive) { qout.od[dst] = qin.od[i]; qout.d2[dst] = qin.d2[i]; qout.tp[dst] = tp; }
     }
 }
@@ -577,7 +606,8 @@ __global__ void k_unpack_hits(SceneDev sc, const float4 *hits, uint32_t n, float
     uint32_t ref = __float_as_uint(h.y), id = 0xFFFFFFFFu;
     if (ref != REF_MISS) {
         uint32_t k = ref_index(ref), type = ref_type(ref);
-        id = type == PRIM_SPHERE ? sc.sph_id[k] : (type == PRIM_QUAD ? sc.quad_id[k] : __float_as_uint(sc.tri[3 * k + 2].y));
+        id = type == PRIM_SPHERE ? __float_as_uint(sc.sph[4 * k + 1].x)
+                                 : (type == PRIM_QUAD ? __float_as_uint(sc.quad[4 * k + 3].x) : __float_as_uint(sc.tri[4 * k + 2].y));
     }
     t[i] = h.x; prim[i] = id; uv[i] = make_float2(h.z, h.w);
 }
@@ -587,35 +617,41 @@ static inline uint32_t grid_for(uint32_t n, uint32_t cap) {
     uint32_t g = (n + 255u) / 256u;
     return g < 1u ? 1u : (g > cap ? cap : g);
 }
+// grids of the queue kernels are whole multiples of the segment count: block b serves segment b % nseg
+static inline uint32_t seg_grid(const FrameDev &f, uint32_t max_rays, uint32_t cap_blocks, uint32_t rays_per_block) {
+    uint32_t per_seg_rays = (max_rays + f.nseg - 1u) / f.nseg;
+    uint32_t per_seg = (per_seg_rays + rays_per_block - 1u) / rays_per_block;
+    uint32_t cap = cap_blocks / f.nseg;
+    if (per_seg > cap) per_seg = cap;
+    if (per_seg < 1u) per_seg = 1u;
+    return per_seg * f.nseg;
+}
 
 void launch_generate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue q, uint32_t *count0) {
     hipLaunchKernelGGL(k_generate, dim3(grid_for(f.nslots * f.npl, lc.cus * 8u)), dim3(256), 0, s, f, q, count0);
 }
 void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q, float4 *hits,
-                      const uint32_t *count, uint32_t *head, Counters *cn, bool bvh, bool stats, uint32_t max_rays) {
+                      const uint32_t *counts, uint32_t *heads, Counters *cn, bool bvh, bool stats, uint32_t max_rays) {
     if (!bvh) {
-        hipLaunchKernelGGL(k_intersect_brute, dim3(grid_for(max_rays, lc.cus * 8u)), dim3(256), 0, s, sc, f, q, hits, count, cn);
+        hipLaunchKernelGGL(k_intersect_brute, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, hits, counts, cn);
         return;
     }
-    uint32_t blocks = lc.cus * lc.isect_blocks_per_cu;
-    uint32_t need = (max_rays + ISECT_CHUNK - 1u) / ISECT_CHUNK;          // one wave per chunk is already enough
-    need = (need + ISECT_WAVES - 1u) / ISECT_WAVES;
-    if (blocks > need) blocks = need < 1u ? 1u : need;
-    if (stats) hipLaunchKernelGGL(k_intersect_bvh<true>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, count, head, cn);
-    else hipLaunchKernelGGL(k_intersect_bvh<false>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, count, head, cn);
+    uint32_t blocks = seg_grid(f, max_rays, lc.cus * lc.isect_blocks_per_cu, ISECT_CHUNK * ISECT_WAVES);
+    if (stats) hipLaunchKernelGGL(k_intersect_bvh<true>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, counts, heads, cn);
+    else hipLaunchKernelGGL(k_intersect_bvh<false>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, counts, heads, cn);
 }
 void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin, const float4 *hits,
                   const uint32_t *count_in, RayQueue qout, uint32_t *count_out, float4 *raw, uint32_t bounce, bool fused,
                   uint32_t max_rays) {
-    dim3 g(grid_for(max_rays, lc.cus * 8u)), b(256);
+    dim3 g(seg_grid(f, max_rays, lc.cus * 8u, 256u)), b(256);
     uint32_t fu = fused ? 1u : 0u;
     if (f.mode == KL_MODE_PT) hipLaunchKernelGGL(k_shade<KL_MODE_PT>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu);
     else if (f.mode == KL_MODE_AO) hipLaunchKernelGGL(k_shade<KL_MODE_AO>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu);
     else hipLaunchKernelGGL(k_shade<KL_MODE_Z>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu);
 }
-void launch_compact(hipStream_t s, const LaunchCfg &lc, RayQueue qin, const uint32_t *count_in, RayQueue qout, uint32_t *count_out,
-                    uint32_t max_rays) {
-    hipLaunchKernelGGL(k_compact, dim3(grid_for(max_rays, lc.cus * 8u)), dim3(256), 0, s, qin, count_in, qout, count_out);
+void launch_compact(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue qin, const uint32_t *count_in, RayQueue qout,
+                    uint32_t *count_out, uint32_t max_rays) {
+    hipLaunchKernelGGL(k_compact, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, f, qin, count_in, qout, count_out);
 }
 void launch_accumulate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, const float4 *raw, float4 *acc, float4 *last_raw,
                        bool camera_change, uint32_t accum_mode) {

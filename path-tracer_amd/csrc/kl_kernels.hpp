@@ -17,7 +17,7 @@ void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, co
 void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin, const float4 *hits,
                   const uint32_t *count_in, RayQueue qout, uint32_t *count_out, float4 *raw, uint32_t bounce, bool fused,
                   uint32_t max_rays);
-void launch_compact(hipStream_t s, const LaunchCfg &lc, RayQueue qin, const uint32_t *count_in, RayQueue qout,
+void launch_compact(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue qin, const uint32_t *count_in, RayQueue qout,
                     uint32_t *count_out, uint32_t max_rays);
 void launch_accumulate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, const float4 *raw, float4 *acc, float4 *last_raw,
                        bool camera_change, uint32_t accum_mode);

@@ -29,20 +29,22 @@ __host__ __device__ inline int make_leaf(uint32_t type, uint32_t start, uint32_t
 constexpr uint32_t MAX_PRIMS_PER_TYPE = 1u << 26;
 constexpr int BVH_MAX_DEPTH = 32;           // builder guarantee == traversal stack entries per lane
 
+// ---- primitive records: 64 bytes each (four float4), leaf order ---------------------
+// The traversal loop fetches "the next 64-byte record" with one group of loads whether the
+// lane stands on an inner node or on a primitive, so nodes and primitives share a size.
+//   sphere: q0 = (c.xyz, r)          q1 = (id bits, material bits, 0, 0)
+//   quad:   q0 = (v0.xyz, v1.x)      q1 = (v1.yz, v2.xy)   q2 = (v2.z, v3.xyz)   q3 = (id bits, material bits, 0, 0)
+//   tri:    q0 = (v0.xyz, e1.x)      q1 = (e1.yz, e2.xy)   q2 = (e2.z, id bits, material bits, 0)
+//           q3 = (n.xyz, 0), n = normalize(cross(e1, e2)) in the shader's arithmetic
+// id = declaration-order primitive id (spheres, then quads, then triangles).
 struct SceneDev {
     const float4 *nodes;     // 4 per node
     int32_t root;            // child reference of the whole scene (node index or leaf), NODE_DONE if empty
     uint32_t n_nodes;
-    // geometry, leaf order
-    const float4 *sph;       // (cx, cy, cz, r)
-    const float4 *quad;      // 3 per quad: (v0.xyz, v1.x) (v1.yz, v2.xy) (v2.z, v3.xyz)
-    const float4 *tri;       // 3 per tri:  (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, id bits, 0, 0)
-    const uint32_t *sph_id;  // declaration-order primitive id (spheres, then quads, then tris)
-    const uint32_t *quad_id;
-    // shading data, leaf order
-    const uint32_t *sph_mat;
-    const uint32_t *quad_mat;
-    const float4 *tri_shade; // 2 per tri: (uv0.xy, uv1.xy) (uv2.xy, material bits, 0)
+    const float4 *sph;       // 4 per sphere
+    const float4 *quad;      // 4 per quad
+    const float4 *tri;       // 4 per triangle
+    const float4 *tri_uv;    // 2 per triangle: (uv0.xy, uv1.xy) (uv2.xy, 0, 0); read for TEXTURED hits only
     const float4 *mats;      // 2 per material: (type bits, r, g, b) (emissive, roughness, ior, 0)
     uint32_t ns, nq, nt, nm;
     // textures, RGBA8, rows as uploaded
@@ -60,12 +62,19 @@ struct FrameDev {
     uint32_t first_frame, nslots;       // frames [first_frame, first_frame + nslots) are in flight
     uint32_t max_bounces, max_frames;
     float eps, max_dist, ao_length, hdri_strength;
+    uint32_t nseg, segcap;              // queue segmentation, see RayQueue
 };
 
 // ---- wavefront queues -------------------------------------------------------------
 // One ray = 40 bytes over three arrays so that every access is a full-width vector load:
 //   od[i] = (o.x, o.y, o.z, d.x)   d2[i] = (d.y, d.z)   tp[i] = (throughput rgb, path id bits)
 // path id = slot * npl + local pixel; it also indexes the raw-frame buffer.
+//
+// A queue is `nseg` independent segments of `segcap` entries: ray i of segment s lives at index
+// s * segcap + i and each segment has its own fill count and its own dequeue head, so the tail
+// atomics of compaction spread over nseg words instead of one. generate deals 64-path groups
+// round-robin over the segments; a survivor always stays in its segment, hence a segment never
+// holds more than it started with and segcap = ceil(paths / nseg) is enough at every bounce.
 struct RayQueue {
     float4 *od;
     float2 *d2;

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Summarises a rocprofv3 rocpd database (the `--kernel-trace --stats` output) into the
+per-kernel table kept under profiles/: calls, total / average / min / max duration, share."""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    m = re.search(r"(k_\w+?)(ILb|ILi|E|$)", name)
+    base = m.group(1) if m else name
+    t = re.search(r"k_\w+?IL([bi])(\d)E", name)
+    return base + ("<%s>" % t.group(2) if t else "")
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else "kernel_name"
+    rows = cur.execute("select %s, start, end from kernels" % name_col).fetchall()
+    agg = {}
+    for name, s, e in rows:
+        k = short(name)
+        a = agg.setdefault(k, [0, 0, 10**18, 0])
+        d = e - s
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    total = sum(a[1] for a in agg.values()) or 1
+    print("| kernel | calls | total ms | avg us | min us | max us | share |")
+    print("|---|---|---|---|---|---|---|")
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("| %s | %d | %.3f | %.1f | %.1f | %.1f | %.1f%% |" % (k, a[0], a[1] / 1e6, a[1] / a[0] / 1e3, a[2] / 1e3, a[3] / 1e3, 100.0 * a[1] / total))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
