@@ -1,0 +1,94 @@
+// kl_bench: headless benchmark / render tool over the C ABI (the reference has no headless mode; its
+// only figure of merit is the 1/frame_time it prints in the window title, GLSL_Renderer.cpp:350-355).
+//
+//   kl_bench --scene builtin --mode pt --w 640 --h 360 --frames 16 --out frame.png
+//   kl_bench --scene synth --blobs 1000 --tris-per-blob 1000 --w 1920 --h 1080 --frames 64 --bounces 8
+//   kl_bench --scene builtin --interactive-demo      (drives the GLSL_Renderer-shaped host class)
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "Math/kl_render.h"
+#include "kl_host.hpp"
+
+using namespace klhost;
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define CK(call) do { kl_status s_ = (call); if (s_ != KL_OK) { std::fprintf(stderr, "%s: %s (%s)\n", #call, kl_status_string(s_), ctx ? kl_last_error(ctx) : ""); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+    std::string scene = "builtin", mode = "pt", out, hdri, albedo;
+    uint32_t w = 1920, h = 1080, frames = 16, bounces = 0, blobs = 1000, tpb = 1000, spheres = 0, warmup = 1, device = 0, fif = 0;
+    bool demo = false;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
+        if (a == "--scene") scene = next(); else if (a == "--mode") mode = next();
+        else if (a == "--w") w = std::atoi(next()); else if (a == "--h") h = std::atoi(next());
+        else if (a == "--frames") frames = std::atoi(next()); else if (a == "--bounces") bounces = std::atoi(next());
+        else if (a == "--blobs") blobs = std::atoi(next()); else if (a == "--tris-per-blob") tpb = std::atoi(next());
+        else if (a == "--spheres") spheres = std::atoi(next()); else if (a == "--warmup") warmup = std::atoi(next());
+        else if (a == "--device") device = std::atoi(next()); else if (a == "--frames-in-flight") fif = std::atoi(next());
+        else if (a == "--out") out = next(); else if (a == "--hdri") hdri = next(); else if (a == "--albedo") albedo = next();
+        else if (a == "--interactive-demo") demo = true;
+        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    if (demo) {
+        // the reference's session in miniature: accumulate, press V (ZDepth), strafe with D, accumulate again
+        GLSL_Renderer r;
+        r.iResolution[0] = w; r.iResolution[1] = h;
+        if (!r.f_init((int)device, hdri, albedo)) { std::fprintf(stderr, "%s\n", r.error.c_str()); return 1; }
+        if (!r.f_run(frames)) { std::fprintf(stderr, "%s\n", r.error.c_str()); return 1; }
+        std::printf("{\"iFrame\": %zu, \"mode\": %d}\n", r.iFrame, (int)r.render_mode);
+        r.key_callback(KEY_V, PRESS); r.key_callback(KEY_V, RELEASE);
+        r.key_callback(KEY_D, PRESS); r.f_frame(); r.key_callback(KEY_D, RELEASE);
+        if (!r.f_run(2)) { std::fprintf(stderr, "%s\n", r.error.c_str()); return 1; }
+        std::printf("{\"iFrame\": %zu, \"mode\": %d, \"camera_x\": %.3f}\n", r.iFrame, (int)r.render_mode, r.camera.position.x);
+        if (!out.empty() && !r.f_save_png(out)) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+        return 0;
+    }
+    kl_ctx *ctx = nullptr;
+    CK(kl_create(&ctx, (int)device, w, h));
+    kl_bvh_stats bs; std::memset(&bs, 0, sizeof bs);
+    if (scene == "builtin") {
+        CK(kl_load_builtin_scene(ctx));
+    } else {
+        kl_synth_params sp = {blobs, tpb, spheres, 1};
+        uint32_t ns, nq, nt, nm;
+        CK(kl_synth_scene_counts(&sp, &ns, &nq, &nt, &nm));
+        std::vector<kl_sphere> s(ns); std::vector<kl_quad> q(nq); std::vector<kl_tri> t(nt); std::vector<kl_material> m(nm);
+        CK(kl_synth_scene_fill(&sp, s.data(), q.data(), t.data(), m.data()));
+        CK(kl_upload_scene(ctx, s.data(), ns, q.data(), nq, t.data(), nt, m.data(), nm));
+    }
+    CK(kl_get_bvh_stats(ctx, &bs));
+    Image img;
+    if (!hdri.empty()) { if (!img.f_load(hdri)) { std::fprintf(stderr, "cannot read %s\n", hdri.c_str()); return 1; } CK(kl_upload_texture(ctx, KL_TEX_HDRI, img.data.data(), img.width, img.height, img.channels)); }
+    if (!albedo.empty()) { if (!img.f_load(albedo)) { std::fprintf(stderr, "cannot read %s\n", albedo.c_str()); return 1; } CK(kl_upload_texture(ctx, KL_TEX_ALBEDO, img.data.data(), img.width, img.height, img.channels)); }
+    kl_params p; kl_default_params(&p);
+    p.max_frames = 0; if (bounces) p.max_bounces = bounces; p.frames_in_flight = fif;
+    CK(kl_set_params(ctx, &p));
+    CK(kl_set_mode(ctx, mode == "ao" ? KL_MODE_AO : (mode == "z" ? KL_MODE_Z : KL_MODE_PT)));
+    for (uint32_t i = 0; i < warmup; i++) { CK(kl_reset(ctx)); CK(kl_render_frames(ctx, frames, 0)); }
+    CK(kl_synchronize(ctx)); CK(kl_reset_counters(ctx)); CK(kl_reset(ctx));
+    double t0 = now_s();
+    CK(kl_render_frames(ctx, frames, 0));
+    CK(kl_synchronize(ctx));
+    double dt = now_s() - t0;
+    kl_counters cn; CK(kl_get_counters(ctx, &cn));
+    std::printf("{\"scene\": \"%s\", \"mode\": \"%s\", \"w\": %u, \"h\": %u, \"frames\": %u, \"bounces\": %u, \"seconds\": %.6f, "
+                "\"samples_per_s\": %.1f, \"mrays_per_s\": %.2f, \"rays_per_sample\": %.3f, \"bvh_nodes\": %u, \"tris\": %u}\n",
+                scene.c_str(), mode.c_str(), w, h, frames, p.max_bounces, dt, (double)cn.paths / dt, (double)cn.rays / dt / 1e6,
+                (double)cn.rays / (double)(cn.paths ? cn.paths : 1), bs.nodes, bs.tris);
+    if (!out.empty()) {
+        std::vector<uint8_t> px((size_t)w * h * 4);
+        CK(kl_resolve(ctx, KL_TONEMAP_CLAMP, px.data(), px.size()));
+        Image o; o.width = (int)w; o.height = (int)h; o.channels = 4; o.data.resize(px.size());
+        for (uint32_t y = 0; y < h; y++) std::memcpy(&o.data[(size_t)w * 4 * (h - 1 - y)], &px[(size_t)w * 4 * y], (size_t)w * 4);
+        if (!o.f_save_png(out)) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+    }
+    kl_destroy(ctx);
+    return 0;
+}

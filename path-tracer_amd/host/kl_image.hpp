@@ -1,0 +1,22 @@
+// 8-bit image I/O for the headless host: the role stb_image plays behind Image::f_load in the
+// reference (source/I-O/File.cpp:13-29): decode to 8-bit, 1/3/4 channels, rows top to bottom, no flip.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace klhost {
+
+struct Image {
+    std::vector<uint8_t> data;
+    int width = 0, height = 0, channels = 0;
+
+    // PNG: 8-bit grey / RGB / RGBA, non-interlaced (what the reference's two textures are). false on failure.
+    bool f_load(const std::string &path);
+    // raw dump written by the tests: width*height*channels bytes
+    bool f_load_raw(const std::string &path, int w, int h, int c);
+    bool f_save_png(const std::string &path) const;
+};
+
+}  // namespace klhost

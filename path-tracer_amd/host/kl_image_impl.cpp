@@ -1,0 +1,124 @@
+// Minimal PNG codec on top of zlib (inflate/deflate + the five scanline filters).
+#include "kl_image.hpp"
+
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace klhost {
+namespace {
+
+uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+void put32(std::vector<uint8_t> &v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+
+bool read_file(const std::string &path, std::vector<uint8_t> &out) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+    if (n < 0) { std::fclose(f); return false; }
+    out.resize((size_t)n);
+    bool ok = std::fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    std::fclose(f);
+    return ok;
+}
+int paeth(int a, int b, int c) {
+    int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+void chunk(std::vector<uint8_t> &png, const char *type, const std::vector<uint8_t> &body) {
+    put32(png, (uint32_t)body.size());
+    size_t start = png.size();
+    png.insert(png.end(), type, type + 4);
+    png.insert(png.end(), body.begin(), body.end());
+    put32(png, (uint32_t)crc32(0L, png.data() + start, (uInt)(png.size() - start)));
+}
+
+}  // namespace
+
+bool Image::f_load(const std::string &path) {
+    std::vector<uint8_t> file;
+    static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    if (!read_file(path, file) || file.size() < 33 || std::memcmp(file.data(), sig, 8) != 0) return false;
+    std::vector<uint8_t> idat;
+    int bit_depth = 0, color = -1, interlace = 0;
+    size_t pos = 8;
+    while (pos + 12 <= file.size()) {
+        uint32_t len = be32(&file[pos]);
+        const char *type = (const char *)&file[pos + 4];
+        if (pos + 12 + len > file.size()) return false;
+        const uint8_t *body = &file[pos + 8];
+        if (!std::memcmp(type, "IHDR", 4) && len >= 13) {
+            width = (int)be32(body); height = (int)be32(body + 4);
+            bit_depth = body[8]; color = body[9]; interlace = body[12];
+        } else if (!std::memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + len);
+        } else if (!std::memcmp(type, "IEND", 4)) break;
+        pos += 12 + len;
+    }
+    if (bit_depth != 8 || interlace != 0 || width <= 0 || height <= 0) return false;
+    channels = color == 0 ? 1 : (color == 2 ? 3 : (color == 6 ? 4 : 0));
+    if (!channels) return false;
+    const size_t stride = (size_t)width * channels;
+    std::vector<uint8_t> raw((stride + 1) * (size_t)height);
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return false;
+    data.assign(stride * (size_t)height, 0);
+    for (int y = 0; y < height; y++) {
+        const uint8_t *in = &raw[(stride + 1) * (size_t)y];
+        uint8_t *out = &data[stride * (size_t)y];
+        const uint8_t *up = y ? out - stride : nullptr;
+        const int filter = in[0];
+        for (size_t i = 0; i < stride; i++) {
+            int a = i >= (size_t)channels ? out[i - channels] : 0;
+            int b = up ? up[i] : 0;
+            int c = (up && i >= (size_t)channels) ? up[i - channels] : 0;
+            int x = in[1 + i];
+            switch (filter) {
+                case 0: break;
+                case 1: x += a; break;
+                case 2: x += b; break;
+                case 3: x += (a + b) / 2; break;
+                case 4: x += paeth(a, b, c); break;
+                default: return false;
+            }
+            out[i] = (uint8_t)x;
+        }
+    }
+    return true;
+}
+
+bool Image::f_load_raw(const std::string &path, int w, int h, int c) {
+    std::vector<uint8_t> file;
+    if (!read_file(path, file) || file.size() != (size_t)w * h * c) return false;
+    data.swap(file); width = w; height = h; channels = c;
+    return true;
+}
+
+bool Image::f_save_png(const std::string &path) const {
+    if (data.empty() || (channels != 1 && channels != 3 && channels != 4)) return false;
+    const size_t stride = (size_t)width * channels;
+    std::vector<uint8_t> raw((stride + 1) * (size_t)height);
+    for (int y = 0; y < height; y++) {
+        raw[(stride + 1) * (size_t)y] = 0;
+        std::memcpy(&raw[(stride + 1) * (size_t)y + 1], &data[stride * (size_t)y], stride);
+    }
+    uLongf clen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+    comp.resize(clen);
+    std::vector<uint8_t> png = {137, 80, 78, 71, 13, 10, 26, 10};
+    std::vector<uint8_t> ihdr;
+    put32(ihdr, (uint32_t)width); put32(ihdr, (uint32_t)height);
+    ihdr.push_back(8); ihdr.push_back(channels == 1 ? 0 : (channels == 3 ? 2 : 6));
+    ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk(png, "IHDR", ihdr); chunk(png, "IDAT", comp); chunk(png, "IEND", {});
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    bool ok = std::fwrite(png.data(), 1, png.size(), f) == png.size();
+    std::fclose(f);
+    return ok;
+}
+
+}  // namespace klhost

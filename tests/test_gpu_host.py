@@ -1,0 +1,41 @@
+"""GPU suite: the compiled headless host (path-tracer_amd/host: GLSL_Renderer-shaped class, PNG codec,
+kl_bench CLI) end to end against the oracle."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import kloracle as ko
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+BENCH = os.path.join(ROOT, "path-tracer_amd", "bin", "kl_bench")
+
+
+def test_kl_bench_renders_the_builtin_scene(tmp_path, oracle_builtin):
+    assert os.path.exists(BENCH), "build the host tool first (make tools)"
+    out = str(tmp_path / "frame.png")
+    res = subprocess.run([BENCH, "--scene", "builtin", "--mode", "pt", "--w", "64", "--h", "36", "--frames", "3", "--warmup", "0",
+                          "--hdri", os.path.join(GOLDEN, "assets", "Background.png"),
+                          "--albedo", os.path.join(GOLDEN, "assets", "Texture.png"), "--out", out],
+                         check=True, capture_output=True, text=True, timeout=120)
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert info["frames"] == 3 and info["samples_per_s"] > 0 and 3 < info["rays_per_sample"] < 9
+    from PIL import Image
+    got = np.array(Image.open(out))
+    p = ko.default_params(width=64, height=36, mode=ko.MODE_PT, max_frames=0)
+    acc = ko.render_mean(oracle_builtin, ko.default_camera(), p, 3)
+    want = ko.resolve(acc)[::-1]                 # PNG rows run top to bottom, buffer rows bottom to top
+    assert np.array_equal(got, want)             # exercises the C++ PNG reader (textures) and writer
+
+
+def test_host_session_follows_the_reference_reset_rules():
+    res = subprocess.run([BENCH, "--interactive-demo", "--w", "48", "--h", "27", "--frames", "5"],
+                         check=True, capture_output=True, text=True, timeout=120)
+    first, second = [json.loads(l) for l in res.stdout.strip().splitlines()]
+    assert first == {"iFrame": 5, "mode": 1}
+    # V switches PATHTRACED -> ZBUFFER and zeroes iFrame; a frame with D held moves the camera by the
+    # move sensitivity (0.15) and restarts again; two more frames follow
+    assert second["mode"] == 2 and second["iFrame"] == 2 and abs(second["camera_x"] - 0.15) < 1e-9
