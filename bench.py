@@ -33,8 +33,8 @@ def load_textures():
     try:
         from PIL import Image
         bg = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "assets", "Background.png")))
-        tx = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "assets", "Texture.png")))
-        return bg, tx, "reference Background.png/Texture.png"
+        tx = np.load(os.path.join(ROOT, "tests", "golden", "assets", "Texture_stb_rgb8.npz"))["rgb"]
+        return bg, tx, "reference Background.png / Texture.png (stb_image-decoded bytes)"
     except Exception:
         rng = np.random.default_rng(0)
         return (rng.integers(0, 256, (2048, 4096, 4), dtype=np.uint8),
@@ -60,16 +60,24 @@ def cpu_baseline(scene_arrays, textures, width, height, bounces, budget_s):
     t0 = time.perf_counter()
     sc.render_raw(cam, p, 0, rows=(mid, mid + 8), nthreads=threads, counters=cn)       # calibration
     dt = max(time.perf_counter() - t0, 1e-3)
-    rows = int(max(8, min(height, 8 * budget_s / dt)))
-    y0 = max(0, mid - rows // 2)
+    rows_budget = max(8.0, 8 * budget_s / dt)
     cn = ko.Counters()
     t0 = time.perf_counter()
-    sc.render_raw(cam, p, 0, rows=(y0, y0 + rows), nthreads=threads, counters=cn)
+    if rows_budget <= height:
+        rows = int(rows_budget)
+        y0 = max(0, mid - rows // 2)
+        sc.render_raw(cam, p, 0, rows=(y0, y0 + rows), nthreads=threads, counters=cn)
+        what = "rows %d..%d of frame 0" % (y0, y0 + rows - 1)
+    else:
+        nframes = int(min(64, max(1, rows_budget // height)))
+        for f in range(nframes):
+            sc.render_raw(cam, p, f, nthreads=threads, counters=cn)
+        what = "frames 0..%d (all rows)" % (nframes - 1)
     dt = time.perf_counter() - t0
     return {"value": cn.paths / dt, "unit": "samples/s", "cores": threads, "kind": "port",
             "mrays_per_s": cn.rays / dt / 1e6, "seconds": round(dt, 2),
-            "sample": "rows %d..%d of frame 0 of the same %dx%d %d-bounce workload (%d paths, %d rays), oracle C port with its own BVH, %d OpenMP threads"
-                      % (y0, y0 + rows - 1, width, height, bounces, cn.paths, cn.rays, threads)}
+            "sample": "%s of the same %dx%d %d-bounce workload (%d paths, %d rays), oracle C port with its own median-split BVH, %d OpenMP threads"
+                      % (what, width, height, bounces, cn.paths, cn.rays, threads)}
 
 
 def main():
@@ -117,20 +125,19 @@ def main():
     bvh = r.bvh_stats()
     r.update_params(max_bounces=args.bounces, max_frames=0, frames_in_flight=args.frames_in_flight,
                     profile_kernels=0 if args.no_profile else 1)
-    if world > 1:
-        r.set_accum_mode(kl.ACCUM_SUM)
     npix = args.width * args.height
-    acc_dev = torch.empty((args.height, args.width, 4), dtype=torch.float32, device="cuda") if world > 1 else None
+    if world > 1:
+        from klrender import dist as kdist
 
     def step():
         # N = 1: frames 0..spp-1 into the running mean, as the reference loop does.
-        # N > 1: rank g owns frames [g*spp, (g+1)*spp); sums are reduced over RCCL and divided.
-        r.reset()
-        r.render_frames(args.spp, first_frame=rank * args.spp)
+        # N > 1: rank g owns frames [g*spp, (g+1)*spp) of a world*spp-sample image; the per-rank
+        #        sums are added with one RCCL all-reduce and divided (klrender/dist.py).
         if world > 1:
-            r.copy_accum_to_device(acc_dev.data_ptr(), acc_dev.numel() * 4)
-            dist.all_reduce(acc_dev, op=dist.ReduceOp.SUM)
-            acc_dev.div_(float(world * args.spp))
+            kdist.render_sample_ranges(r, world * args.spp)
+        else:
+            r.reset()
+            r.render_frames(args.spp, first_frame=0)
         r.synchronize()
 
     # algorithmic bytes per ray: one instrumented, untimed pass over a few frames

@@ -20,7 +20,8 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 #define CK(call) do { kl_status s_ = (call); if (s_ != KL_OK) { std::fprintf(stderr, "%s: %s (%s)\n", #call, kl_status_string(s_), ctx ? kl_last_error(ctx) : ""); return 1; } } while (0)
 
 int main(int argc, char **argv) {
-    std::string scene = "builtin", mode = "pt", out, hdri, albedo;
+    std::string scene = "builtin", mode = "pt", out, hdri, albedo, albedo_raw;
+    int araw[3] = {0, 0, 0};
     uint32_t w = 1920, h = 1080, frames = 16, bounces = 0, blobs = 1000, tpb = 1000, spheres = 0, warmup = 1, device = 0, fif = 0;
     bool demo = false;
     for (int i = 1; i < argc; i++) {
@@ -33,6 +34,7 @@ int main(int argc, char **argv) {
         else if (a == "--spheres") spheres = std::atoi(next()); else if (a == "--warmup") warmup = std::atoi(next());
         else if (a == "--device") device = std::atoi(next()); else if (a == "--frames-in-flight") fif = std::atoi(next());
         else if (a == "--out") out = next(); else if (a == "--hdri") hdri = next(); else if (a == "--albedo") albedo = next();
+        else if (a == "--albedo-raw") { albedo_raw = next(); for (int k = 0; k < 3; k++) araw[k] = std::atoi(next()); }
         else if (a == "--interactive-demo") demo = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -67,6 +69,7 @@ int main(int argc, char **argv) {
     Image img;
     if (!hdri.empty()) { if (!img.f_load(hdri)) { std::fprintf(stderr, "cannot read %s\n", hdri.c_str()); return 1; } CK(kl_upload_texture(ctx, KL_TEX_HDRI, img.data.data(), img.width, img.height, img.channels)); }
     if (!albedo.empty()) { if (!img.f_load(albedo)) { std::fprintf(stderr, "cannot read %s\n", albedo.c_str()); return 1; } CK(kl_upload_texture(ctx, KL_TEX_ALBEDO, img.data.data(), img.width, img.height, img.channels)); }
+    if (!albedo_raw.empty()) { if (!img.f_load_raw(albedo_raw, araw[0], araw[1], araw[2])) { std::fprintf(stderr, "cannot read %s\n", albedo_raw.c_str()); return 1; } CK(kl_upload_texture(ctx, KL_TEX_ALBEDO, img.data.data(), img.width, img.height, img.channels)); }
     kl_params p; kl_default_params(&p);
     p.max_frames = 0; if (bounces) p.max_bounces = bounces; p.frames_in_flight = fif;
     CK(kl_set_params(ctx, &p));

@@ -17,11 +17,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def textures():
-    """The two images the reference host loads (GLSL_Renderer.cpp:237,240), decoded
-    to 8-bit arrays with rows top-to-bottom, exactly as stb_image hands them over."""
+    """The two images the reference host loads (GLSL_Renderer.cpp:237,240) as 8-bit arrays with rows
+    top-to-bottom, exactly as stb_image hands them over: the environment is a lossless PNG; the albedo
+    ("Texture.png" is JPEG data) is kept as the bytes stb_image decodes (tests/golden/make_golden.py)."""
     from PIL import Image
     bg = np.array(Image.open(os.path.join(GOLDEN, "assets", "Background.png")))
-    tx = np.array(Image.open(os.path.join(GOLDEN, "assets", "Texture.png")))
+    tx = np.load(os.path.join(GOLDEN, "assets", "Texture_stb_rgb8.npz"))["rgb"]
     assert bg.shape == (2048, 4096, 4) and tx.shape == (1080, 1920, 3)
     return {"hdri": bg, "albedo": tx}
 

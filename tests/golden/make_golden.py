@@ -46,14 +46,23 @@ def run_ref(w, h, mode, first_frame, nframes, textures, bounces=None, samples=No
 def main():
     if not os.path.exists(BIN):
         sys.exit("build oracle/_ref/glsl_ref first: make -C oracle ref")
-    # the two data files the reference host loads (GLSL_Renderer.cpp:237,240), kept as test data
-    for name in ("Background.png", "Texture.png"):
-        shutil.copyfile(os.path.join(REF, "resources", name), os.path.join(HERE, "assets", name))
-    bg = np.array(Image.open(os.path.join(HERE, "assets", "Background.png")))
-    tx = np.array(Image.open(os.path.join(HERE, "assets", "Texture.png")))
+    # The two data files the reference host loads (GLSL_Renderer.cpp:237,240), decoded with the
+    # stb_image.h the reference vendors (what Image::f_load calls), kept as test data. Background.png
+    # is a real PNG (lossless: any decoder gives these bytes) and is kept as a file; "Texture.png" is
+    # JPEG data under a .png name, whose pixels depend on the decoder, so its stb-decoded bytes are
+    # what is kept (1.7 % of its bytes differ from a libjpeg decode, by up to 3).
+    stb = os.path.join(ROOT, "oracle", "_ref", "stb_decode")
     bg_raw, tx_raw = os.path.join(TMP, "kl_bg.raw"), os.path.join(TMP, "kl_tx.raw")
-    bg.tofile(bg_raw)
-    tx.tofile(tx_raw)
+    shapes = {}
+    for name, raw in (("Background.png", bg_raw), ("Texture.png", tx_raw)):
+        out = subprocess.run([stb, os.path.join(REF, "resources", name), raw], check=True, stdout=subprocess.PIPE, text=True).stdout
+        w, h, c = map(int, out.split())
+        shapes[name] = (h, w, c)
+    shutil.copyfile(os.path.join(REF, "resources", "Background.png"), os.path.join(HERE, "assets", "Background.png"))
+    bg = np.fromfile(bg_raw, dtype=np.uint8).reshape(shapes["Background.png"])
+    tx = np.fromfile(tx_raw, dtype=np.uint8).reshape(shapes["Texture.png"])
+    assert np.array_equal(bg, np.array(Image.open(os.path.join(HERE, "assets", "Background.png"))))
+    np.savez_compressed(os.path.join(HERE, "assets", "Texture_stb_rgb8.npz"), rgb=tx)
     tex = {"hdri": (bg_raw, bg.shape[1], bg.shape[0], bg.shape[2]),
            "albedo": (tx_raw, tx.shape[1], tx.shape[0], tx.shape[2])}
     manifest = {"generator": "tests/golden/make_golden.py", "harness": "oracle/ref_harness.c",

@@ -14,12 +14,14 @@ pytestmark = pytest.mark.gpu
 BENCH = os.path.join(ROOT, "path-tracer_amd", "bin", "kl_bench")
 
 
-def test_kl_bench_renders_the_builtin_scene(tmp_path, oracle_builtin):
+def test_kl_bench_renders_the_builtin_scene(tmp_path, oracle_builtin, textures):
     assert os.path.exists(BENCH), "build the host tool first (make tools)"
     out = str(tmp_path / "frame.png")
+    alb = str(tmp_path / "albedo.raw")
+    textures["albedo"].tofile(alb)
     res = subprocess.run([BENCH, "--scene", "builtin", "--mode", "pt", "--w", "64", "--h", "36", "--frames", "3", "--warmup", "0",
                           "--hdri", os.path.join(GOLDEN, "assets", "Background.png"),
-                          "--albedo", os.path.join(GOLDEN, "assets", "Texture.png"), "--out", out],
+                          "--albedo-raw", alb, "1920", "1080", "3", "--out", out],
                          check=True, capture_output=True, text=True, timeout=120)
     info = json.loads(res.stdout.strip().splitlines()[-1])
     assert info["frames"] == 3 and info["samples_per_s"] > 0 and 3 < info["rays_per_sample"] < 9
@@ -37,5 +39,5 @@ def test_host_session_follows_the_reference_reset_rules():
     first, second = [json.loads(l) for l in res.stdout.strip().splitlines()]
     assert first == {"iFrame": 5, "mode": 1}
     # V switches PATHTRACED -> ZBUFFER and zeroes iFrame; a frame with D held moves the camera by the
-    # move sensitivity (0.15) and restarts again; two more frames follow
-    assert second["mode"] == 2 and second["iFrame"] == 2 and abs(second["camera_x"] - 0.15) < 1e-9
+    # move sensitivity (0.15) and restarts again (that frame is iFrame 0); two more frames follow
+    assert second["mode"] == 2 and second["iFrame"] == 3 and abs(second["camera_x"] - 0.15) < 1e-9
