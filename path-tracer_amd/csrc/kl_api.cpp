@@ -285,7 +285,10 @@ kl_status kl_create(kl_ctx **out, int32_t device, uint32_t width, uint32_t heigh
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->lc.cus = (uint32_t)prop.multiProcessorCount;
-    c->lc.isect_blocks_per_cu = 5;   // 4 waves x 8 KiB of traversal stack each -> five workgroups fill a CU's 160 KiB LDS
+#ifndef KL_ISECT_BLOCKS_PER_CU
+#define KL_ISECT_BLOCKS_PER_CU 5     // 4 waves x 8 KiB of traversal stack each -> five workgroups fill a CU's 160 KiB LDS
+#endif
+    c->lc.isect_blocks_per_cu = KL_ISECT_BLOCKS_PER_CU;
     c->width = width; c->height = height;
     kl_default_camera(&c->cam);
     kl_default_params(&c->params);
@@ -389,7 +392,10 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     KL_HIP(c, hipStreamSynchronize(c->stream));
     HostBVH bvh;
     unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    build_bvh(s, ns, q, nq, t, nt, bvh, threads);
+    // scenes small enough for the flat loop keep everything in one list; otherwise primitives whose box is
+    // >= 2 % of the scene's (at most 32 of them: walls, floors, sky domes) are tested outside the tree
+    const bool small = ns + nq + nt <= KL_BRUTE_AUTO_LIMIT;
+    build_bvh(s, ns, q, nq, t, nt, bvh, threads, small ? 0.0f : 0.02f, 32);
     // leaf-ordered 64-byte primitive records (layout: kl_types.hpp)
     auto bits = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
     std::vector<float4> sph((size_t)ns * 4), quad((size_t)nq * 4), tri((size_t)nt * 4), tuv((size_t)nt * 2), mats((size_t)nm * 2);
@@ -435,6 +441,7 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     c->sc.sph = c->d_sph.p; c->sc.quad = c->d_quad.p; c->sc.tri = c->d_tri.p;
     c->sc.tri_uv = c->d_tri_uv.p; c->sc.mats = c->d_mats.p;
     c->sc.ns = ns; c->sc.nq = nq; c->sc.nt = nt; c->sc.nm = nm;
+    for (int k = 0; k < 3; k++) { c->sc.flat_start[k] = bvh.flat_start[k]; c->sc.flat_count[k] = bvh.flat_count[k]; }
     c->n_prims = ns + nq + nt;
     c->bvh_stats = bvh.stats;
     c->bvh_stats.prim_bytes = ((uint64_t)ns + nq + nt) * 64;

@@ -171,12 +171,14 @@ void identity_order(uint32_t ns, uint32_t nq, uint32_t nt, HostBVH &out) {
     for (uint32_t i = 0; i < nt; i++) out.tri_order[i] = i;
     std::memset(&out.stats, 0, sizeof out.stats);
     out.stats.spheres = ns; out.stats.quads = nq; out.stats.tris = nt;
+    out.flat_start[PRIM_SPHERE] = ns; out.flat_start[PRIM_QUAD] = nq; out.flat_start[PRIM_TRI] = nt;
+    out.flat_count[0] = out.flat_count[1] = out.flat_count[2] = 0;
 }
 
 void build_bvh(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
-               HostBVH &out, unsigned threads) {
+               HostBVH &out, unsigned threads, float flat_fraction, uint32_t max_flat) {
     auto t0 = std::chrono::steady_clock::now();
-    const uint32_t n = ns + nq + nt;
+    uint32_t n = ns + nq + nt;
     identity_order(0, 0, 0, out);
     out.stats.spheres = ns; out.stats.quads = nq; out.stats.tris = nt;
     if (n == 0) return;
@@ -200,9 +202,21 @@ void build_bvh(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, c
         pad_box(p.box);
         for (int k = 0; k < 3; k++) p.c[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
     }
-    B.nodes.resize(n); B.leaves.resize(n);
+    // split off the flat primitives: [0, n) stays in the tree, [n, n_all) is flat
+    const uint32_t n_all = n;
+    if (flat_fraction > 0.0f && max_flat > 0) {
+        const float limit = flat_fraction * B.bounds(0, n_all).area();
+        auto mid = std::partition(B.prims.begin(), B.prims.end(), [limit](const Prim &p) { return !(p.box.area() >= limit); });
+        uint32_t first_flat = (uint32_t)(mid - B.prims.begin());
+        if (n_all - first_flat > max_flat) {      // keep only the largest max_flat; the others rejoin the tree
+            std::sort(B.prims.begin() + first_flat, B.prims.end(), [](const Prim &a, const Prim &b) { return a.box.area() < b.box.area(); });
+            first_flat = n_all - max_flat;
+        }
+        n = first_flat;
+    }
+    B.nodes.resize(n + 1); B.leaves.resize(n + 1);
     B.max_tasks = threads > 1 ? (int)threads - 1 : 0;
-    int32_t root = B.build(0, n, 0);
+    int32_t root = n ? B.build(0, n, 0) : 0;
 
     // flatten depth-first; leaves append their primitives to the per-type leaf order
     const uint32_t nn = B.n_nodes.load();
@@ -212,10 +226,10 @@ void build_bvh(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, c
     double sah = 0.0;
     struct Item { int32_t tmp; int32_t *slot; uint32_t depth; };
     std::vector<Item> stack;
-    int32_t root_ref = 0;
-    stack.push_back({root, &root_ref, 0});
+    int32_t root_ref = NODE_DONE;
+    if (n) stack.push_back({root, &root_ref, 0});
     std::vector<int32_t> child_store((size_t)nn * 2);
-    Box rootbox = B.bounds(0, n);
+    Box rootbox = B.bounds(0, n ? n : n_all);
     const float root_area = std::max(rootbox.area(), 1e-30f);
     while (!stack.empty()) {
         Item it = stack.back(); stack.pop_back();
@@ -245,6 +259,15 @@ void build_bvh(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, c
     for (uint32_t i = 0; i < nn; i++) {
         std::memcpy(&out.nodes[(size_t)i * 16 + 12], &child_store[(size_t)i * 2], 4);
         std::memcpy(&out.nodes[(size_t)i * 16 + 13], &child_store[(size_t)i * 2 + 1], 4);
+    }
+    // flat primitives close each order array
+    out.flat_start[PRIM_SPHERE] = (uint32_t)out.sph_order.size();
+    out.flat_start[PRIM_QUAD] = (uint32_t)out.quad_order.size();
+    out.flat_start[PRIM_TRI] = (uint32_t)out.tri_order.size();
+    for (uint32_t i = n; i < n_all; i++) {
+        const Prim &p = B.prims[i];
+        (p.type == PRIM_SPHERE ? out.sph_order : (p.type == PRIM_QUAD ? out.quad_order : out.tri_order)).push_back(p.index);
+        out.flat_count[p.type]++;
     }
     out.root = root_ref;
     out.stats.nodes = nn; out.stats.leaves = n_leaves; out.stats.max_depth = max_depth; out.stats.max_leaf_size = max_leaf;

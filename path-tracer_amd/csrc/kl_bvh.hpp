@@ -16,6 +16,7 @@ struct HostBVH {
     std::vector<uint32_t> sph_order;     // leaf position -> index into the uploaded sphere array
     std::vector<uint32_t> quad_order;
     std::vector<uint32_t> tri_order;
+    uint32_t flat_start[3], flat_count[3];   // flat primitives close each order array (indexed by PRIM_*)
     kl_bvh_stats stats;
 };
 
@@ -23,8 +24,12 @@ struct HostBVH {
 // lies deeper than BVH_MAX_DEPTH inner nodes, so a traversal stack of that many entries cannot
 // overflow; leaf boxes are widened by a few ulps of their coordinates so that rounding in the
 // slab test cannot cull a primitive the exact arithmetic would reach.
+// Primitives whose box area is at least `flat_fraction` of the scene box area (at most `max_flat`, largest
+// first) are left out of the tree and appended to their order array ("flat" primitives): giant primitives
+// wreck a SAH tree, and testing a handful of them coherently for every ray is cheaper than meeting them
+// in divergent leaves. flat_fraction <= 0 disables this.
 void build_bvh(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
-               HostBVH &out, unsigned threads);
+               HostBVH &out, unsigned threads, float flat_fraction, uint32_t max_flat);
 
 // No tree: identity ordering, root = NODE_DONE (flat-loop kernel only).
 void identity_order(uint32_t ns, uint32_t nq, uint32_t nt, HostBVH &out);

@@ -197,13 +197,54 @@ __global__ __launch_bounds__(256) void k_intersect_brute(SceneDev sc, FrameDev f
     }
 }
 
+// ------------------------------------------------------------------ intersect: flat primitives
+// The few scene-spanning primitives kept out of the tree, tested for every ray in queue order (uniform
+// loads, no divergence). Writes the hit record that k_intersect_bvh then starts from, so the traversal
+// begins with the ray already clipped by the walls.
+__global__ __launch_bounds__(256) void k_intersect_flat(SceneDev sc, FrameDev f, RayQueue q, float4 *hits,
+                                                        const uint32_t *counts, Counters *cn, uint32_t stats) {
+    const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
+    const uint32_t count = counts[seg];
+    if (stats && sub == 0 && threadIdx.x == 0 && count) {
+        atomicAdd(&cn->sphere_tests, (unsigned long long)count * sc.flat_count[PRIM_SPHERE]);
+        atomicAdd(&cn->quad_tests, (unsigned long long)count * sc.flat_count[PRIM_QUAD]);
+        atomicAdd(&cn->tri_tests, (unsigned long long)count * sc.flat_count[PRIM_TRI]);
+    }
+    for (uint32_t r = sub * blockDim.x + threadIdx.x; r < count; r += nsub * blockDim.x) {
+        const uint32_t i = seg * f.segcap + r;
+        float4 od = q.od[i]; float2 d2 = q.d2[i];
+        v3 o = V(od.x, od.y, od.z), d = V(od.w, d2.x, d2.y);
+        Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
+        if (ray_finite(o, d)) {
+            for (uint32_t k = sc.flat_start[PRIM_SPHERE]; k < sc.flat_start[PRIM_SPHERE] + sc.flat_count[PRIM_SPHERE]; k++)
+                test_sphere(sc.sph[4 * k], sc.sph[4 * k + 1], k, o, d, f.eps, h);
+            for (uint32_t k = sc.flat_start[PRIM_QUAD]; k < sc.flat_start[PRIM_QUAD] + sc.flat_count[PRIM_QUAD]; k++)
+                test_quad(sc.quad[4 * k], sc.quad[4 * k + 1], sc.quad[4 * k + 2], sc.quad[4 * k + 3], k, o, d, h);
+            for (uint32_t k = sc.flat_start[PRIM_TRI]; k < sc.flat_start[PRIM_TRI] + sc.flat_count[PRIM_TRI]; k++)
+                test_tri(sc.tri[4 * k], sc.tri[4 * k + 1], sc.tri[4 * k + 2], k, o, d, h);
+        }
+        hits[i] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
+    }
+}
+
+// declaration-order id of a primitive reference (read from its record)
+__device__ __forceinline__ uint32_t ref_id(const SceneDev &sc, uint32_t ref) {
+    uint32_t k = ref_index(ref), type = ref_type(ref);
+    return type == PRIM_SPHERE ? __float_as_uint(sc.sph[4 * k + 1].x)
+                               : (type == PRIM_QUAD ? __float_as_uint(sc.quad[4 * k + 3].x) : __float_as_uint(sc.tri[4 * k + 2].y));
+}
+
 // ------------------------------------------------------------------ intersect: BVH
 constexpr uint32_t ISECT_WAVES = 4;          // waves per workgroup
 constexpr uint32_t ISECT_CHUNK = 256;        // rays a wave takes from the global counter at a time
-constexpr uint32_t ISECT_REFILL = 40;        // refill idle lanes when fewer than this many are active
+#ifndef KL_ISECT_REFILL
+#define KL_ISECT_REFILL 40
+#endif
+constexpr uint32_t ISECT_REFILL = KL_ISECT_REFILL;   // refill idle lanes when fewer than this many are active
 
+// `seeded`: hits[] already holds the closest flat-primitive hit of every ray (k_intersect_flat ran).
 template <bool STATS>
-__global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc, FrameDev f, RayQueue q, float4 *hits,
+__global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc, FrameDev f, RayQueue q, float4 *hits, uint32_t seeded,
                                                                    const uint32_t *counts, uint32_t *heads, Counters *cn) {
     // per-lane traversal stack: entry e of lane l of wave w at [w][e][l] -> consecutive lanes hit consecutive banks
     __shared__ int stack[ISECT_WAVES][BVH_MAX_DEPTH][64];
@@ -244,6 +285,11 @@ __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc,
                 float4 od = q.od[ray]; float2 d2 = q.d2[ray];
                 o = V(od.x, od.y, od.z); d = V(od.w, d2.x, d2.y);
                 h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
+                if (seeded) {
+                    float4 hr = hits[ray];
+                    h.t = hr.x; h.ref = __float_as_uint(hr.y); h.u = hr.z; h.v = hr.w;
+                    if (h.ref != REF_MISS) h.id = ref_id(sc, h.ref);    // needed only to break exact ties
+                }
                 // slab reciprocals; a zero component is nudged so 0 * inf never appears
                 float sx = fabsf(d.x) > 1e-20f ? d.x : copysignf(1e-20f, d.x);
                 float sy = fabsf(d.y) > 1e-20f ? d.y : copysignf(1e-20f, d.y);
@@ -253,8 +299,8 @@ __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc,
                 sp = 0;
                 node = sc.root;
                 active = true;
-                if (node == NODE_DONE || !ray_finite(o, d)) {    // empty scene, or a NaN ray: hits nothing
-                    hits[ray] = make_float4(h.t, __uint_as_float(REF_MISS), 0.0f, 0.0f);
+                if (node == NODE_DONE || !ray_finite(o, d)) {    // empty tree, or a NaN ray (hits nothing)
+                    if (!seeded) hits[ray] = make_float4(h.t, __uint_as_float(REF_MISS), 0.0f, 0.0f);
                     active = false;
                 }
             }
@@ -604,11 +650,7 @@ __global__ void k_unpack_hits(SceneDev sc, const float4 *hits, uint32_t n, float
     if (i >= n) return;
     float4 h = hits[i];
     uint32_t ref = __float_as_uint(h.y), id = 0xFFFFFFFFu;
-    if (ref != REF_MISS) {
-        uint32_t k = ref_index(ref), type = ref_type(ref);
-        id = type == PRIM_SPHERE ? __float_as_uint(sc.sph[4 * k + 1].x)
-                                 : (type == PRIM_QUAD ? __float_as_uint(sc.quad[4 * k + 3].x) : __float_as_uint(sc.tri[4 * k + 2].y));
-    }
+    if (ref != REF_MISS) id = ref_id(sc, ref);
     t[i] = h.x; prim[i] = id; uv[i] = make_float2(h.z, h.w);
 }
 
@@ -636,9 +678,12 @@ void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, co
         hipLaunchKernelGGL(k_intersect_brute, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, hits, counts, cn);
         return;
     }
+    const uint32_t seeded = (sc.flat_count[0] + sc.flat_count[1] + sc.flat_count[2]) ? 1u : 0u;
+    if (seeded)
+        hipLaunchKernelGGL(k_intersect_flat, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, hits, counts, cn, stats ? 1u : 0u);
     uint32_t blocks = seg_grid(f, max_rays, lc.cus * lc.isect_blocks_per_cu, ISECT_CHUNK * ISECT_WAVES);
-    if (stats) hipLaunchKernelGGL(k_intersect_bvh<true>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, counts, heads, cn);
-    else hipLaunchKernelGGL(k_intersect_bvh<false>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, counts, heads, cn);
+    if (stats) hipLaunchKernelGGL(k_intersect_bvh<true>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, seeded, counts, heads, cn);
+    else hipLaunchKernelGGL(k_intersect_bvh<false>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, seeded, counts, heads, cn);
 }
 void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin, const float4 *hits,
                   const uint32_t *count_in, RayQueue qout, uint32_t *count_out, float4 *raw, uint32_t bounce, bool fused,

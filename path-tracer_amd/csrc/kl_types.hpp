@@ -27,7 +27,10 @@ __host__ __device__ inline int make_leaf(uint32_t type, uint32_t start, uint32_t
     return ~(int)((type << 29) | ((count - 1u) << 26) | start);
 }
 constexpr uint32_t MAX_PRIMS_PER_TYPE = 1u << 26;
-constexpr int BVH_MAX_DEPTH = 32;           // builder guarantee == traversal stack entries per lane
+#ifndef KL_BVH_MAX_DEPTH
+#define KL_BVH_MAX_DEPTH 32
+#endif
+constexpr int BVH_MAX_DEPTH = KL_BVH_MAX_DEPTH;   // builder guarantee == traversal stack entries per lane
 
 // ---- primitive records: 64 bytes each (four float4), leaf order ---------------------
 // The traversal loop fetches "the next 64-byte record" with one group of loads whether the
@@ -47,6 +50,10 @@ struct SceneDev {
     const float4 *tri_uv;    // 2 per triangle: (uv0.xy, uv1.xy) (uv2.xy, 0, 0); read for TEXTURED hits only
     const float4 *mats;      // 2 per material: (type bits, r, g, b) (emissive, roughness, ior, 0)
     uint32_t ns, nq, nt, nm;
+    // "flat" primitives: the few whose box spans a large part of the scene (walls, floor). They are kept
+    // out of the tree, sit at the end of their type's array, and are tested for every ray by a coherent
+    // pass (k_intersect_flat) whose result seeds the traversal's closest distance.
+    uint32_t flat_start[3], flat_count[3];   // indexed by PRIM_*
     // textures, RGBA8, rows as uploaded
     const uchar4 *tex[2];
     uint32_t tex_w[2], tex_h[2];

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libklrender.so")
+# KLRENDER_LIB selects another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("KLRENDER_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libklrender.so")
 
 MODE_AO, MODE_PT, MODE_Z = 0, 1, 2
 DIFFUSE, GLASS, EMISSIVE, TEXTURED = 0, 1, 2, 3
