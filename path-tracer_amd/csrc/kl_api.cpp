@@ -70,6 +70,7 @@ struct kl_ctx {
     DevBuf<float2> d_d2[2];
     DevBuf<uint32_t> d_qctl;          // count[0..B], head[0..B]
     DevBuf<Counters> d_counters;
+    DevBuf<int> d_overflow;           // traversal stack entries beyond the LDS part
     DevBuf<uchar4> d_resolve;
     // bookkeeping
     uint64_t frames_total = 0, paths_total = 0;
@@ -138,6 +139,7 @@ kl_status ensure_buffers(kl_ctx *c) {
         KL_HIP(c, c->d_counters.alloc(1));
         KL_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream));
     }
+    KL_HIP(c, c->d_overflow.alloc(intersect_overflow_ints(c->lc)));
     return KL_OK;
 }
 
@@ -200,7 +202,7 @@ kl_status timed_intersect(kl_ctx *c, const FrameDev &f, RayQueue q, uint32_t *co
         a = get_event(c); b = get_event(c);
         if (a && b) KL_HIP(c, hipEventRecord(a, c->stream));
     }
-    launch_intersect(c->stream, c->lc, c->sc, f, q, c->d_hits.p, count, head, c->d_counters.p, use_bvh(c),
+    launch_intersect(c->stream, c->lc, c->sc, f, q, c->d_hits.p, count, head, c->d_counters.p, c->d_overflow.p, use_bvh(c),
                      c->params.collect_stats != 0, max_rays);
     if (a && b) { KL_HIP(c, hipEventRecord(b, c->stream)); c->pending.push_back({a, b, 0}); }
     return KL_OK;
@@ -315,7 +317,7 @@ kl_status kl_destroy(kl_ctx *c) {
     c->d_mats.release();
     for (int k = 0; k < 2; k++) { c->d_tex[k].release(); c->d_od[k].release(); c->d_d2[k].release(); c->d_tp[k].release(); }
     c->d_hits.release(); c->d_raw.release(); c->d_acc.release(); c->d_last_raw.release();
-    c->d_qctl.release(); c->d_counters.release(); c->d_resolve.release();
+    c->d_qctl.release(); c->d_counters.release(); c->d_resolve.release(); c->d_overflow.release();
     (void)hipStreamDestroy(c->stream);
     delete c;
     return KL_OK;
@@ -430,6 +432,7 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
         mats[2 * (size_t)k + 1] = make_float4(m[k].emissive, m[k].roughness, m[k].ior, 0.0f);
     }
     kl_status st;
+    if (bvh.nodes.size() < 16) bvh.nodes.resize(16, 0.0f);    // idle lanes of the cooperative fetch read one record from here
     if ((st = upload(c, c->d_nodes, bvh.nodes.data(), bvh.nodes.size() / 4)) != KL_OK) return st;
     if ((st = upload(c, c->d_sph, sph.data(), sph.size())) != KL_OK) return st;
     if ((st = upload(c, c->d_quad, quad.data(), quad.size())) != KL_OK) return st;
@@ -586,6 +589,7 @@ kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, f
     KL_HIP(c, b_od.alloc(n)); KL_HIP(c, b_hits.alloc(n)); KL_HIP(c, b_d2.alloc(n)); KL_HIP(c, b_uv.alloc(n));
     KL_HIP(c, b_t.alloc(n)); KL_HIP(c, b_prim.alloc(n)); KL_HIP(c, b_ctl.alloc(2));
     if (!c->d_counters.p) { KL_HIP(c, c->d_counters.alloc(1)); KL_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream)); }
+    KL_HIP(c, c->d_overflow.alloc(intersect_overflow_ints(c->lc)));
     const uint32_t ctl[2] = { n, 0 };
     KL_HIP(c, hipMemcpyAsync(b_od.p, od.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     KL_HIP(c, hipMemcpyAsync(b_d2.p, d2.data(), n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
@@ -593,7 +597,7 @@ kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, f
     FrameDev f = make_frame(c, 0, 1);
     f.nseg = 1; f.segcap = n;                       // caller rays form one segment
     RayQueue q = { b_od.p, b_d2.p, nullptr };
-    launch_intersect(c->stream, c->lc, c->sc, f, q, b_hits.p, &b_ctl.p[0], &b_ctl.p[1], c->d_counters.p, use_bvh(c),
+    launch_intersect(c->stream, c->lc, c->sc, f, q, b_hits.p, &b_ctl.p[0], &b_ctl.p[1], c->d_counters.p, c->d_overflow.p, use_bvh(c),
                      c->params.collect_stats != 0, n);
     launch_unpack_hits(c->stream, c->sc, b_hits.p, n, b_t.p, b_prim.p, b_uv.p);
     KL_HIP(c, hipMemcpyAsync(t, b_t.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));

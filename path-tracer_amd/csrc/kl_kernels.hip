@@ -240,16 +240,54 @@ constexpr uint32_t ISECT_CHUNK = 256;        // rays a wave takes from the globa
 #ifndef KL_ISECT_REFILL
 #define KL_ISECT_REFILL 40
 #endif
+#ifndef KL_ISECT_COOP
+#define KL_ISECT_COOP 1            // quad-cooperative LDS-DMA record fetch (0: every lane loads its own record)
+#endif
+#ifndef KL_ISECT_LDS_STACK
+#define KL_ISECT_LDS_STACK 15      // stack entries per lane kept in LDS; 15 + the staging area lets five workgroups share a CU
+#endif
 constexpr uint32_t ISECT_REFILL = KL_ISECT_REFILL;   // refill idle lanes when fewer than this many are active
 
 // `seeded`: hits[] already holds the closest flat-primitive hit of every ray (k_intersect_flat ran).
+//
+// Record fetch. A lane needs the 64 bytes of "its" record every step. Fetched by the lane itself that is four
+// 16-byte loads whose 64 lanes touch 64 different lines each: the L1 tag pipeline (about one line per clock
+// per CU) becomes the limiter. Instead the four lanes of a quad fetch each other's records: load k of the
+// wave brings, for every quad, the record of quad-lane k, one 16-byte slice per lane, so an instruction
+// touches 16 lines instead of 64. The loads are LDS-DMA (`global_load_lds_dwordx4`: per-lane source, LDS
+// destination = wave base + lane * 16), which lands each record contiguously; the lane then reads its own
+// record back with four ds_read_b128. Regions of the four loads are 1040 bytes apart so that those reads
+// are bank-conflict free.
+//
+// Stack. The first ISECT_LDS_STACK entries of a lane's traversal stack live in LDS ([wave][entry][lane]:
+// consecutive lanes on consecutive banks); deeper entries (rare) spill to a per-wave slab in global memory.
+constexpr uint32_t ISECT_LDS_STACK = KL_ISECT_LDS_STACK;
+constexpr uint32_t ISECT_OVF_STACK = BVH_MAX_DEPTH > ISECT_LDS_STACK ? BVH_MAX_DEPTH - ISECT_LDS_STACK : 1;
+constexpr uint32_t STAGE_REGION_F4 = 65;      // 64 float4 (1 KiB) of payload + 16 bytes of skew per region
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+template <int K>
+__device__ __forceinline__ void coop_fetch_one(int alo, int ahi, uint32_t slice, float4 *region) {
+    // address of quad-lane K's record, broadcast over the quad with a DPP quad_perm
+    const int blo = __builtin_amdgcn_mov_dpp(alo, K * 0x55, 0xf, 0xf, false);
+    const int bhi = __builtin_amdgcn_mov_dpp(ahi, K * 0x55, 0xf, 0xf, false);
+    const uintptr_t a = ((uintptr_t)(uint32_t)bhi << 32) | (uintptr_t)(uint32_t)blo;
+    __builtin_amdgcn_global_load_lds((glb_void_t *)(a + slice), (lds_void_t *)region, 16, 0, 0);
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc, FrameDev f, RayQueue q, float4 *hits, uint32_t seeded,
-                                                                   const uint32_t *counts, uint32_t *heads, Counters *cn) {
-    // per-lane traversal stack: entry e of lane l of wave w at [w][e][l] -> consecutive lanes hit consecutive banks
-    __shared__ int stack[ISECT_WAVES][BVH_MAX_DEPTH][64];
+                                                                   const uint32_t *counts, uint32_t *heads, Counters *cn, int *overflow) {
+    __shared__ int stack[ISECT_WAVES][ISECT_LDS_STACK][64];
+#if KL_ISECT_COOP
+    __shared__ float4 stage[ISECT_WAVES][4][STAGE_REGION_F4];
+#endif
     const uint32_t lane = lane_id();
-    int *st = &stack[threadIdx.x >> 6][0][lane];
+    const uint32_t wave_in_block = threadIdx.x >> 6;
+    int *st = &stack[wave_in_block][0][lane];
+    int *ovf = overflow + ((size_t)(blockIdx.x * ISECT_WAVES + wave_in_block) * ISECT_OVF_STACK) * 64u + lane;
     // this workgroup serves queue segment blockIdx % nseg; its waves pull ray chunks from that segment's head
     const uint32_t seg = blockIdx.x % f.nseg;
     const uint32_t count = counts[seg];
@@ -314,13 +352,29 @@ __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc,
         // lane (an inner node or one primitive of the current leaf) with a single group of loads, so a
         // wave pays one memory latency per step whatever mix of nodes and primitives its lanes are on.
         do {
+            const bool inner = node >= 0;
+            const uint32_t lv = (uint32_t)~node;
+            const uint32_t type = (lv >> 29) & 3u, start = lv & 0x3FFFFFFu;
+            const float4 *rec = inner ? sc.nodes + 4u * (uint32_t)node
+                                      : (type == PRIM_TRI ? sc.tri : (type == PRIM_SPHERE ? sc.sph : sc.quad)) + 4u * start;
+#if KL_ISECT_COOP
+            // all 64 lanes take part (a quad serves its busy members); an idle lane names the first node
+            const uintptr_t my = (uintptr_t)(active ? rec : sc.nodes);
+            const int alo = (int)(uint32_t)my, ahi = (int)(uint32_t)(my >> 32);
+            const uint32_t slice = (lane & 3u) << 4;
+            float4 *regions = &stage[wave_in_block][0][0];
+            coop_fetch_one<0>(alo, ahi, slice, regions);
+            coop_fetch_one<1>(alo, ahi, slice, regions + STAGE_REGION_F4);
+            coop_fetch_one<2>(alo, ahi, slice, regions + 2 * STAGE_REGION_F4);
+            coop_fetch_one<3>(alo, ahi, slice, regions + 3 * STAGE_REGION_F4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float4 *mine = &stage[wave_in_block][lane & 3u][(lane >> 2) * 4u];
+            const float4 n0 = mine[0], n1 = mine[1], n2 = mine[2], n3 = mine[3];
+#endif
             if (active) {
-                const bool inner = node >= 0;
-                const uint32_t lv = (uint32_t)~node;
-                const uint32_t type = (lv >> 29) & 3u, start = lv & 0x3FFFFFFu;
-                const float4 *rec = inner ? sc.nodes + 4u * (uint32_t)node
-                                          : (type == PRIM_TRI ? sc.tri : (type == PRIM_SPHERE ? sc.sph : sc.quad)) + 4u * start;
+#if !KL_ISECT_COOP
                 const float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+#endif
                 bool pop = false;
                 if (inner) {
                     if (STATS) s_nodes++;
@@ -339,7 +393,9 @@ __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc,
                     if (hit0 && hit1) {
                         bool swap = t1n < t0n;
                         int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                        st[sp * 64] = farc; sp++;
+                        if ((uint32_t)sp < ISECT_LDS_STACK) st[sp * 64] = farc;
+                        else ovf[((uint32_t)sp - ISECT_LDS_STACK) * 64u] = farc;
+                        sp++;
                         node = nearc;
                     } else if (hit0) node = c0;
                     else if (hit1) node = c1;
@@ -352,8 +408,10 @@ __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc,
                     else pop = true;
                 }
                 if (pop) {
-                    if (sp > 0) { sp--; node = st[sp * 64]; }
-                    else { hits[ray] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v); active = false; }
+                    if (sp > 0) {
+                        sp--;
+                        node = (uint32_t)sp < ISECT_LDS_STACK ? st[sp * 64] : ovf[((uint32_t)sp - ISECT_LDS_STACK) * 64u];
+                    } else { hits[ray] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v); active = false; }
                 }
             }
             am = __ballot(active);
@@ -672,8 +730,11 @@ static inline uint32_t seg_grid(const FrameDev &f, uint32_t max_rays, uint32_t c
 void launch_generate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue q, uint32_t *count0) {
     hipLaunchKernelGGL(k_generate, dim3(grid_for(f.nslots * f.npl, lc.cus * 8u)), dim3(256), 0, s, f, q, count0);
 }
+size_t intersect_overflow_ints(const LaunchCfg &lc) {
+    return (size_t)lc.cus * lc.isect_blocks_per_cu * ISECT_WAVES * ISECT_OVF_STACK * 64u;
+}
 void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q, float4 *hits,
-                      const uint32_t *counts, uint32_t *heads, Counters *cn, bool bvh, bool stats, uint32_t max_rays) {
+                      const uint32_t *counts, uint32_t *heads, Counters *cn, int *overflow, bool bvh, bool stats, uint32_t max_rays) {
     if (!bvh) {
         hipLaunchKernelGGL(k_intersect_brute, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, hits, counts, cn);
         return;
@@ -682,8 +743,8 @@ void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, co
     if (seeded)
         hipLaunchKernelGGL(k_intersect_flat, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, hits, counts, cn, stats ? 1u : 0u);
     uint32_t blocks = seg_grid(f, max_rays, lc.cus * lc.isect_blocks_per_cu, ISECT_CHUNK * ISECT_WAVES);
-    if (stats) hipLaunchKernelGGL(k_intersect_bvh<true>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, seeded, counts, heads, cn);
-    else hipLaunchKernelGGL(k_intersect_bvh<false>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, seeded, counts, heads, cn);
+    if (stats) hipLaunchKernelGGL(k_intersect_bvh<true>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, seeded, counts, heads, cn, overflow);
+    else hipLaunchKernelGGL(k_intersect_bvh<false>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, seeded, counts, heads, cn, overflow);
 }
 void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin, const float4 *hits,
                   const uint32_t *count_in, RayQueue qout, uint32_t *count_out, float4 *raw, uint32_t bounce, bool fused,
