@@ -61,7 +61,7 @@ struct kl_ctx {
     uint32_t n_prims = 0;
     SceneDev sc;
     kl_bvh_stats bvh_stats;
-    DevBuf<float4> d_nodes, d_sph, d_quad, d_tri, d_tri_uv, d_mats;
+    DevBuf<float4> d_rec, d_tri_uv, d_mats;
     DevBuf<uchar4> d_tex[2];
     // wavefront state
     uint32_t slots = 0;               // frames in flight the buffers are sized for
@@ -313,8 +313,7 @@ kl_status kl_destroy(kl_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (const EventPair &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
-    c->d_nodes.release(); c->d_sph.release(); c->d_quad.release(); c->d_tri.release(); c->d_tri_uv.release();
-    c->d_mats.release();
+    c->d_rec.release(); c->d_tri_uv.release(); c->d_mats.release();
     for (int k = 0; k < 2; k++) { c->d_tex[k].release(); c->d_od[k].release(); c->d_d2[k].release(); c->d_tp[k].release(); }
     c->d_hits.release(); c->d_raw.release(); c->d_acc.release(); c->d_last_raw.release();
     c->d_qctl.release(); c->d_counters.release(); c->d_resolve.release(); c->d_overflow.release();
@@ -385,8 +384,8 @@ kl_status kl_upload_texture(kl_ctx *c, uint32_t which, const uint8_t *px, uint32
 kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq,
                           const kl_tri *t, uint32_t nt, const kl_material *m, uint32_t nm) {
     if (!c || (ns && !s) || (nq && !q) || (nt && !t) || !m || nm == 0) return fail(c, KL_E_INVALID, "null scene array");
-    if (ns >= MAX_PRIMS_PER_TYPE || nq >= MAX_PRIMS_PER_TYPE || nt >= MAX_PRIMS_PER_TYPE)
-        return fail(c, KL_E_LIMIT, "at most 2^26 primitives per type");
+    if ((uint64_t)ns + nq + nt >= MAX_RECORDS / 2)
+        return fail(c, KL_E_LIMIT, "at most 2^25 primitives (nodes + primitives share 2^26 records)");
     for (uint32_t i = 0; i < ns; i++) if (s[i].material >= nm) return fail(c, KL_E_INVALID, "sphere material index out of range");
     for (uint32_t i = 0; i < nq; i++) if (q[i].material >= nm) return fail(c, KL_E_INVALID, "quad material index out of range");
     for (uint32_t i = 0; i < nt; i++) if (t[i].material >= nm) return fail(c, KL_E_INVALID, "triangle material index out of range");
@@ -398,31 +397,50 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     // >= 2 % of the scene's (at most 32 of them: walls, floors, sky domes) are tested outside the tree
     const bool small = ns + nq + nt <= KL_BRUTE_AUTO_LIMIT;
     build_bvh(s, ns, q, nq, t, nt, bvh, threads, small ? 0.0f : 0.02f, 32);
-    // leaf-ordered 64-byte primitive records (layout: kl_types.hpp)
+    // one array of 64-byte records: nodes, then spheres, quads, triangles in leaf order (layout: kl_types.hpp)
     auto bits = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
-    std::vector<float4> sph((size_t)ns * 4), quad((size_t)nq * 4), tri((size_t)nt * 4), tuv((size_t)nt * 2), mats((size_t)nm * 2);
+    const uint32_t n_nodes = bvh.stats.nodes;
+    const uint32_t base[3] = { n_nodes, n_nodes + ns, n_nodes + ns + nq };
+    const size_t n_rec = std::max<size_t>((size_t)n_nodes + ns + nq + nt, 1);   // record 0 always exists
+    if (n_rec >= MAX_RECORDS) return fail(c, KL_E_LIMIT, "nodes + primitives exceed 2^26 records");
+    std::vector<float4> rec(n_rec * 4, make_float4(0, 0, 0, 0)), tuv((size_t)nt * 2), mats((size_t)nm * 2);
+    auto patch_child = [&](int32_t child) -> int32_t {        // builder leaves count within their type
+        if (child >= 0 || child == NODE_DONE) return child;
+        uint32_t lv = (uint32_t)~child, type = (lv >> 29) & 3u, cnt = ((lv >> 26) & 7u) + 1u, start = lv & 0x3FFFFFFu;
+        return make_leaf(type, base[type] + start, cnt);
+    };
+    for (uint32_t k = 0; k < n_nodes; k++) {
+        const float *nd = &bvh.nodes[(size_t)k * 16];
+        int32_t c0, c1; std::memcpy(&c0, nd + 12, 4); std::memcpy(&c1, nd + 13, 4);
+        rec[4 * (size_t)k] = make_float4(nd[0], nd[1], nd[2], nd[3]);
+        rec[4 * (size_t)k + 1] = make_float4(nd[4], nd[5], nd[6], nd[7]);
+        rec[4 * (size_t)k + 2] = make_float4(nd[8], nd[9], nd[10], nd[11]);
+        rec[4 * (size_t)k + 3] = make_float4(bits((uint32_t)patch_child(c0)), bits((uint32_t)patch_child(c1)), 0.0f, 0.0f);
+    }
     for (uint32_t k = 0; k < ns; k++) {
         const kl_sphere &x = s[bvh.sph_order[k]];
-        sph[4 * (size_t)k] = make_float4(x.center[0], x.center[1], x.center[2], x.radius);
-        sph[4 * (size_t)k + 1] = make_float4(bits(bvh.sph_order[k]), bits(x.material), 0.0f, 0.0f);
-        sph[4 * (size_t)k + 2] = sph[4 * (size_t)k + 3] = make_float4(0, 0, 0, 0);
+        float4 *r = &rec[4 * ((size_t)base[PRIM_SPHERE] + k)];
+        r[0] = make_float4(x.center[0], x.center[1], x.center[2], x.radius);
+        r[1] = make_float4(bits(bvh.sph_order[k]), bits(x.material), 0.0f, 0.0f);
     }
     for (uint32_t k = 0; k < nq; k++) {
         const kl_quad &x = q[bvh.quad_order[k]];
-        quad[4 * (size_t)k] = make_float4(x.v0[0], x.v0[1], x.v0[2], x.v1[0]);
-        quad[4 * (size_t)k + 1] = make_float4(x.v1[1], x.v1[2], x.v2[0], x.v2[1]);
-        quad[4 * (size_t)k + 2] = make_float4(x.v2[2], x.v3[0], x.v3[1], x.v3[2]);
-        quad[4 * (size_t)k + 3] = make_float4(bits(ns + bvh.quad_order[k]), bits(x.material), 0.0f, 0.0f);
+        float4 *r = &rec[4 * ((size_t)base[PRIM_QUAD] + k)];
+        r[0] = make_float4(x.v0[0], x.v0[1], x.v0[2], x.v1[0]);
+        r[1] = make_float4(x.v1[1], x.v1[2], x.v2[0], x.v2[1]);
+        r[2] = make_float4(x.v2[2], x.v3[0], x.v3[1], x.v3[2]);
+        r[3] = make_float4(bits(ns + bvh.quad_order[k]), bits(x.material), 0.0f, 0.0f);
     }
     for (uint32_t k = 0; k < nt; k++) {
         const kl_tri &x = t[bvh.tri_order[k]];
         v3 v0 = V(x.v0[0], x.v0[1], x.v0[2]);
         v3 e1 = V(x.v1[0], x.v1[1], x.v1[2]) - v0, e2 = V(x.v2[0], x.v2[1], x.v2[2]) - v0;
         v3 nor = normalize(cross(e1, e2));       // the flat shading normal, in the arithmetic the shade stage would use
-        tri[4 * (size_t)k] = make_float4(v0.x, v0.y, v0.z, e1.x);
-        tri[4 * (size_t)k + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-        tri[4 * (size_t)k + 2] = make_float4(e2.z, bits(ns + nq + bvh.tri_order[k]), bits(x.material), 0.0f);
-        tri[4 * (size_t)k + 3] = make_float4(nor.x, nor.y, nor.z, 0.0f);
+        float4 *r = &rec[4 * ((size_t)base[PRIM_TRI] + k)];
+        r[0] = make_float4(v0.x, v0.y, v0.z, e1.x);
+        r[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+        r[2] = make_float4(e2.z, bits(ns + nq + bvh.tri_order[k]), bits(x.material), 0.0f);
+        r[3] = make_float4(nor.x, nor.y, nor.z, 0.0f);
         tuv[2 * (size_t)k] = make_float4(x.uv0[0], x.uv0[1], x.uv1[0], x.uv1[1]);
         tuv[2 * (size_t)k + 1] = make_float4(x.uv2[0], x.uv2[1], 0.0f, 0.0f);
     }
@@ -432,19 +450,17 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
         mats[2 * (size_t)k + 1] = make_float4(m[k].emissive, m[k].roughness, m[k].ior, 0.0f);
     }
     kl_status st;
-    if (bvh.nodes.size() < 16) bvh.nodes.resize(16, 0.0f);    // idle lanes of the cooperative fetch read one record from here
-    if ((st = upload(c, c->d_nodes, bvh.nodes.data(), bvh.nodes.size() / 4)) != KL_OK) return st;
-    if ((st = upload(c, c->d_sph, sph.data(), sph.size())) != KL_OK) return st;
-    if ((st = upload(c, c->d_quad, quad.data(), quad.size())) != KL_OK) return st;
-    if ((st = upload(c, c->d_tri, tri.data(), tri.size())) != KL_OK) return st;
+    if ((st = upload(c, c->d_rec, rec.data(), rec.size())) != KL_OK) return st;
     if ((st = upload(c, c->d_tri_uv, tuv.data(), tuv.size())) != KL_OK) return st;
     if ((st = upload(c, c->d_mats, mats.data(), mats.size())) != KL_OK) return st;
     KL_HIP(c, hipStreamSynchronize(c->stream));     // the host vectors go out of scope below
-    c->sc.nodes = c->d_nodes.p; c->sc.root = bvh.root; c->sc.n_nodes = bvh.stats.nodes;
-    c->sc.sph = c->d_sph.p; c->sc.quad = c->d_quad.p; c->sc.tri = c->d_tri.p;
-    c->sc.tri_uv = c->d_tri_uv.p; c->sc.mats = c->d_mats.p;
-    c->sc.ns = ns; c->sc.nq = nq; c->sc.nt = nt; c->sc.nm = nm;
-    for (int k = 0; k < 3; k++) { c->sc.flat_start[k] = bvh.flat_start[k]; c->sc.flat_count[k] = bvh.flat_count[k]; }
+    c->sc.rec = c->d_rec.p; c->sc.root = patch_child(bvh.root); c->sc.n_nodes = n_nodes;
+    c->sc.tri_uv = c->d_tri_uv.p; c->sc.mats = c->d_mats.p; c->sc.nm = nm;
+    c->sc.count[PRIM_SPHERE] = ns; c->sc.count[PRIM_QUAD] = nq; c->sc.count[PRIM_TRI] = nt;
+    for (int k = 0; k < 3; k++) {
+        c->sc.base[k] = base[k];
+        c->sc.flat_start[k] = base[k] + bvh.flat_start[k]; c->sc.flat_count[k] = bvh.flat_count[k];
+    }
     c->n_prims = ns + nq + nt;
     c->bvh_stats = bvh.stats;
     c->bvh_stats.prim_bytes = ((uint64_t)ns + nq + nt) * 64;
@@ -466,7 +482,7 @@ kl_status kl_get_bvh_stats(kl_ctx *c, kl_bvh_stats *out) {
 }
 kl_status kl_synth_scene_counts(const kl_synth_params *sp, uint32_t *ns, uint32_t *nq, uint32_t *nt, uint32_t *nm) {
     if (!sp || !ns || !nq || !nt || !nm || sp->tris_per_blob < 12) return KL_E_INVALID;
-    if ((uint64_t)sp->blobs * sp->tris_per_blob >= MAX_PRIMS_PER_TYPE || sp->analytic_spheres >= MAX_PRIMS_PER_TYPE) return KL_E_LIMIT;
+    if ((uint64_t)sp->blobs * sp->tris_per_blob + sp->analytic_spheres >= MAX_RECORDS / 2) return KL_E_LIMIT;
     synth_counts(*sp, *ns, *nq, *nt, *nm);
     return KL_OK;
 }

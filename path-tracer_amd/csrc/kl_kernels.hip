@@ -134,6 +134,15 @@ __device__ __forceinline__ void test_tri(float4 a, float4 b, float4 c, uint32_t 
     if (tri_intersect(o, d, V(a.x, a.y, a.z), V(a.w, b.x, b.y), V(b.z, b.w, c.x), t, u, v))
         accept(h, t, make_ref(PRIM_TRI, i), __float_as_uint(c.y), u, v);
 }
+// all primitives of one type in record range [first, first + n): uniform loads (flat loop, flat pass)
+__device__ __forceinline__ void test_range(const SceneDev &sc, uint32_t type, uint32_t first, uint32_t n, v3 o, v3 d, float eps, Hit &h) {
+    for (uint32_t r = first; r < first + n; r++) {
+        const float4 *p = sc.rec + 4u * r;
+        if (type == PRIM_SPHERE) test_sphere(p[0], p[1], r, o, d, eps, h);
+        else if (type == PRIM_QUAD) test_quad(p[0], p[1], p[2], p[3], r, o, d, h);
+        else test_tri(p[0], p[1], p[2], r, o, d, h);
+    }
+}
 __device__ __forceinline__ bool ray_finite(v3 o, v3 d) {
     const float inf = __builtin_huge_valf();
     return fabsf(o.x) < inf && fabsf(o.y) < inf && fabsf(o.z) < inf && fabsf(d.x) < inf && fabsf(d.y) < inf && fabsf(d.z) < inf;
@@ -189,9 +198,9 @@ __global__ __launch_bounds__(256) void k_intersect_brute(SceneDev sc, FrameDev f
         v3 o = V(od.x, od.y, od.z), d = V(od.w, d2.x, d2.y);
         Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
         if (ray_finite(o, d)) {
-            for (uint32_t k = 0; k < sc.ns; k++) test_sphere(sc.sph[4 * k], sc.sph[4 * k + 1], k, o, d, f.eps, h);
-            for (uint32_t k = 0; k < sc.nq; k++) test_quad(sc.quad[4 * k], sc.quad[4 * k + 1], sc.quad[4 * k + 2], sc.quad[4 * k + 3], k, o, d, h);
-            for (uint32_t k = 0; k < sc.nt; k++) test_tri(sc.tri[4 * k], sc.tri[4 * k + 1], sc.tri[4 * k + 2], k, o, d, h);
+            test_range(sc, PRIM_SPHERE, sc.base[PRIM_SPHERE], sc.count[PRIM_SPHERE], o, d, f.eps, h);
+            test_range(sc, PRIM_QUAD, sc.base[PRIM_QUAD], sc.count[PRIM_QUAD], o, d, f.eps, h);
+            test_range(sc, PRIM_TRI, sc.base[PRIM_TRI], sc.count[PRIM_TRI], o, d, f.eps, h);
         }
         hits[i] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
     }
@@ -216,12 +225,9 @@ __global__ __launch_bounds__(256) void k_intersect_flat(SceneDev sc, FrameDev f,
         v3 o = V(od.x, od.y, od.z), d = V(od.w, d2.x, d2.y);
         Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
         if (ray_finite(o, d)) {
-            for (uint32_t k = sc.flat_start[PRIM_SPHERE]; k < sc.flat_start[PRIM_SPHERE] + sc.flat_count[PRIM_SPHERE]; k++)
-                test_sphere(sc.sph[4 * k], sc.sph[4 * k + 1], k, o, d, f.eps, h);
-            for (uint32_t k = sc.flat_start[PRIM_QUAD]; k < sc.flat_start[PRIM_QUAD] + sc.flat_count[PRIM_QUAD]; k++)
-                test_quad(sc.quad[4 * k], sc.quad[4 * k + 1], sc.quad[4 * k + 2], sc.quad[4 * k + 3], k, o, d, h);
-            for (uint32_t k = sc.flat_start[PRIM_TRI]; k < sc.flat_start[PRIM_TRI] + sc.flat_count[PRIM_TRI]; k++)
-                test_tri(sc.tri[4 * k], sc.tri[4 * k + 1], sc.tri[4 * k + 2], k, o, d, h);
+            test_range(sc, PRIM_SPHERE, sc.flat_start[PRIM_SPHERE], sc.flat_count[PRIM_SPHERE], o, d, f.eps, h);
+            test_range(sc, PRIM_QUAD, sc.flat_start[PRIM_QUAD], sc.flat_count[PRIM_QUAD], o, d, f.eps, h);
+            test_range(sc, PRIM_TRI, sc.flat_start[PRIM_TRI], sc.flat_count[PRIM_TRI], o, d, f.eps, h);
         }
         hits[i] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
     }
@@ -229,9 +235,9 @@ __global__ __launch_bounds__(256) void k_intersect_flat(SceneDev sc, FrameDev f,
 
 // declaration-order id of a primitive reference (read from its record)
 __device__ __forceinline__ uint32_t ref_id(const SceneDev &sc, uint32_t ref) {
-    uint32_t k = ref_index(ref), type = ref_type(ref);
-    return type == PRIM_SPHERE ? __float_as_uint(sc.sph[4 * k + 1].x)
-                               : (type == PRIM_QUAD ? __float_as_uint(sc.quad[4 * k + 3].x) : __float_as_uint(sc.tri[4 * k + 2].y));
+    const float4 *p = sc.rec + 4u * ref_record(ref);
+    const uint32_t type = ref_type(ref);
+    return type == PRIM_SPHERE ? __float_as_uint(p[1].x) : (type == PRIM_QUAD ? __float_as_uint(p[3].x) : __float_as_uint(p[2].y));
 }
 
 // ------------------------------------------------------------------ intersect: BVH
@@ -269,12 +275,10 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
 template <int K>
-__device__ __forceinline__ void coop_fetch_one(int alo, int ahi, uint32_t slice, float4 *region) {
-    // address of quad-lane K's record, broadcast over the quad with a DPP quad_perm
-    const int blo = __builtin_amdgcn_mov_dpp(alo, K * 0x55, 0xf, 0xf, false);
-    const int bhi = __builtin_amdgcn_mov_dpp(ahi, K * 0x55, 0xf, 0xf, false);
-    const uintptr_t a = ((uintptr_t)(uint32_t)bhi << 32) | (uintptr_t)(uint32_t)blo;
-    __builtin_amdgcn_global_load_lds((glb_void_t *)(a + slice), (lds_void_t *)region, 16, 0, 0);
+__device__ __forceinline__ void coop_fetch_one(const float4 *base, uint32_t my_offset, uint32_t slice, float4 *region) {
+    // byte offset of quad-lane K's record, broadcast over the quad with a DPP quad_perm
+    const uint32_t off = (uint32_t)__builtin_amdgcn_mov_dpp((int)my_offset, K * 0x55, 0xf, 0xf, false) + slice;
+    __builtin_amdgcn_global_load_lds((glb_void_t *)((const char *)base + off), (lds_void_t *)region, 16, 0, 0);
 }
 
 template <bool STATS>
@@ -355,24 +359,23 @@ __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc,
             const bool inner = node >= 0;
             const uint32_t lv = (uint32_t)~node;
             const uint32_t type = (lv >> 29) & 3u, start = lv & 0x3FFFFFFu;
-            const float4 *rec = inner ? sc.nodes + 4u * (uint32_t)node
-                                      : (type == PRIM_TRI ? sc.tri : (type == PRIM_SPHERE ? sc.sph : sc.quad)) + 4u * start;
+            const uint32_t record = inner ? (uint32_t)node : start;
 #if KL_ISECT_COOP
-            // all 64 lanes take part (a quad serves its busy members); an idle lane names the first node
-            const uintptr_t my = (uintptr_t)(active ? rec : sc.nodes);
-            const int alo = (int)(uint32_t)my, ahi = (int)(uint32_t)(my >> 32);
+            // all 64 lanes take part (a quad serves its busy members); an idle lane names record 0
+            const uint32_t my_offset = active ? record << 6 : 0u;
             const uint32_t slice = (lane & 3u) << 4;
             float4 *regions = &stage[wave_in_block][0][0];
-            coop_fetch_one<0>(alo, ahi, slice, regions);
-            coop_fetch_one<1>(alo, ahi, slice, regions + STAGE_REGION_F4);
-            coop_fetch_one<2>(alo, ahi, slice, regions + 2 * STAGE_REGION_F4);
-            coop_fetch_one<3>(alo, ahi, slice, regions + 3 * STAGE_REGION_F4);
+            coop_fetch_one<0>(sc.rec, my_offset, slice, regions);
+            coop_fetch_one<1>(sc.rec, my_offset, slice, regions + STAGE_REGION_F4);
+            coop_fetch_one<2>(sc.rec, my_offset, slice, regions + 2 * STAGE_REGION_F4);
+            coop_fetch_one<3>(sc.rec, my_offset, slice, regions + 3 * STAGE_REGION_F4);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const float4 *mine = &stage[wave_in_block][lane & 3u][(lane >> 2) * 4u];
             const float4 n0 = mine[0], n1 = mine[1], n2 = mine[2], n3 = mine[3];
 #endif
             if (active) {
 #if !KL_ISECT_COOP
+                const float4 *rec = sc.rec + 4u * record;
                 const float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
 #endif
                 bool pop = false;
@@ -439,8 +442,8 @@ struct Surf { v3 pos, n; bool inside; uint32_t mat; float u, v; };
 __device__ __forceinline__ Surf surface(const SceneDev &sc, v3 o, v3 d, float t, uint32_t ref, float hu, float hv) {
     Surf s;
     s.pos = o + d * t;                                             // RF:304,318
-    uint32_t i = ref_index(ref), type = ref_type(ref);
-    const float4 *rec = (type == PRIM_TRI ? sc.tri : (type == PRIM_SPHERE ? sc.sph : sc.quad)) + 4u * i;
+    const uint32_t type = ref_type(ref);
+    const float4 *rec = sc.rec + 4u * ref_record(ref);
     const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
     if (type == PRIM_SPHERE) {
         v3 ctr = V(a.x, a.y, a.z);
@@ -570,7 +573,8 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
                         if (mtype == KL_TEXTURED) {
                             float tu = s.u, tv = s.v;
                             if (ref_type(ref) == PRIM_TRI) {
-                                float4 s0 = sc.tri_uv[2 * ref_index(ref)], s1 = sc.tri_uv[2 * ref_index(ref) + 1];
+                                const uint32_t ti = ref_record(ref) - sc.base[PRIM_TRI];
+                                float4 s0 = sc.tri_uv[2 * ti], s1 = sc.tri_uv[2 * ti + 1];
                                 float w = (1.0f - s.u) - s.v;
                                 tu = (s0.x * w + s0.z * s.u) + s1.x * s.v;
                                 tv = (s0.y * w + s0.w * s.u) + s1.y * s.v;

@@ -7,53 +7,53 @@
 
 namespace kl {
 
-// ---- primitive references ---------------------------------------------------
-// A hit names its primitive by (type, index into that type's leaf-ordered array).
-enum : uint32_t { PRIM_SPHERE = 0, PRIM_QUAD = 1, PRIM_TRI = 2 };
-constexpr uint32_t REF_MISS = 0xFFFFFFFFu;
-__host__ __device__ inline uint32_t make_ref(uint32_t type, uint32_t index) { return (type << 30) | index; }
-__host__ __device__ inline uint32_t ref_type(uint32_t r) { return r >> 30; }
-__host__ __device__ inline uint32_t ref_index(uint32_t r) { return r & 0x3FFFFFFFu; }
-
-// ---- BVH node: 64 bytes, 64-byte aligned, four float4 -------------------------
-//   q0 = (lo0.x, lo0.y, lo0.z, hi0.x)   q1 = (hi0.y, hi0.z, lo1.x, lo1.y)
-//   q2 = (lo1.z, hi1.x, hi1.y, hi1.z)   q3 = (child0, child1, 0, 0) as int bits
-// child >= 0: index of an inner node. child < 0: leaf, ~child =
-//   (type << 29) | ((count-1) << 26) | start, a run of `count` (1..8) primitives
-//   of one type starting at `start` in that type's leaf-ordered array.
-constexpr int NODE_DONE = 0x7FFFFFFF;       // "stack empty" marker, never a valid node index
-constexpr uint32_t LEAF_MAX = 8;
-__host__ __device__ inline int make_leaf(uint32_t type, uint32_t start, uint32_t count) {
-    return ~(int)((type << 29) | ((count - 1u) << 26) | start);
-}
-constexpr uint32_t MAX_PRIMS_PER_TYPE = 1u << 26;
-#ifndef KL_BVH_MAX_DEPTH
-#define KL_BVH_MAX_DEPTH 32
-#endif
-constexpr int BVH_MAX_DEPTH = KL_BVH_MAX_DEPTH;   // builder guarantee == traversal stack entries per lane
-
-// ---- primitive records: 64 bytes each (four float4), leaf order ---------------------
-// The traversal loop fetches "the next 64-byte record" with one group of loads whether the
-// lane stands on an inner node or on a primitive, so nodes and primitives share a size.
+// ---- records ------------------------------------------------------------------------
+// Everything the traversal touches lives in ONE array of 64-byte records (four float4 each):
+// first the BVH nodes, then the spheres, the quads and the triangles in leaf order. A record is
+// named by its index in that array, so its address is base + (index << 6): 32-bit arithmetic, one
+// scalar base. The traversal loop fetches "the next record" with one group of loads whether the
+// lane stands on an inner node or on a primitive.
+//   node:   q0 = (lo0.x, lo0.y, lo0.z, hi0.x)   q1 = (hi0.y, hi0.z, lo1.x, lo1.y)
+//           q2 = (lo1.z, hi1.x, hi1.y, hi1.z)   q3 = (child0, child1, 0, 0) as int bits
 //   sphere: q0 = (c.xyz, r)          q1 = (id bits, material bits, 0, 0)
 //   quad:   q0 = (v0.xyz, v1.x)      q1 = (v1.yz, v2.xy)   q2 = (v2.z, v3.xyz)   q3 = (id bits, material bits, 0, 0)
 //   tri:    q0 = (v0.xyz, e1.x)      q1 = (e1.yz, e2.xy)   q2 = (e2.z, id bits, material bits, 0)
 //           q3 = (n.xyz, 0), n = normalize(cross(e1, e2)) in the shader's arithmetic
 // id = declaration-order primitive id (spheres, then quads, then triangles).
+// child >= 0: record index of an inner node. child < 0: leaf, ~child =
+//   (type << 29) | ((count-1) << 26) | start: a run of `count` (1..8) primitives of one type whose
+//   first record is `start`.
+// A hit names its primitive by (type << 30) | record index.
+enum : uint32_t { PRIM_SPHERE = 0, PRIM_QUAD = 1, PRIM_TRI = 2 };
+constexpr uint32_t REF_MISS = 0xFFFFFFFFu;
+__host__ __device__ inline uint32_t make_ref(uint32_t type, uint32_t record) { return (type << 30) | record; }
+__host__ __device__ inline uint32_t ref_type(uint32_t r) { return r >> 30; }
+__host__ __device__ inline uint32_t ref_record(uint32_t r) { return r & 0x3FFFFFFFu; }
+
+constexpr int NODE_DONE = 0x7FFFFFFF;       // "stack empty" marker, never a valid node index
+constexpr uint32_t LEAF_MAX = 8;
+__host__ __device__ inline int make_leaf(uint32_t type, uint32_t start, uint32_t count) {
+    return ~(int)((type << 29) | ((count - 1u) << 26) | start);
+}
+constexpr uint32_t MAX_RECORDS = 1u << 26;  // nodes + primitives
+#ifndef KL_BVH_MAX_DEPTH
+#define KL_BVH_MAX_DEPTH 32
+#endif
+constexpr int BVH_MAX_DEPTH = KL_BVH_MAX_DEPTH;   // builder guarantee == traversal stack entries per lane
+
 struct SceneDev {
-    const float4 *nodes;     // 4 per node
-    int32_t root;            // child reference of the whole scene (node index or leaf), NODE_DONE if empty
+    const float4 *rec;       // the record array
+    int32_t root;            // child reference of the whole tree (node index or leaf), NODE_DONE if the tree is empty
     uint32_t n_nodes;
-    const float4 *sph;       // 4 per sphere
-    const float4 *quad;      // 4 per quad
-    const float4 *tri;       // 4 per triangle
-    const float4 *tri_uv;    // 2 per triangle: (uv0.xy, uv1.xy) (uv2.xy, 0, 0); read for TEXTURED hits only
-    const float4 *mats;      // 2 per material: (type bits, r, g, b) (emissive, roughness, ior, 0)
-    uint32_t ns, nq, nt, nm;
+    uint32_t base[3];        // first record of each primitive type (indexed by PRIM_*)
+    uint32_t count[3];       // primitives of each type
     // "flat" primitives: the few whose box spans a large part of the scene (walls, floor). They are kept
-    // out of the tree, sit at the end of their type's array, and are tested for every ray by a coherent
+    // out of the tree, sit at the end of their type's records, and are tested for every ray by a coherent
     // pass (k_intersect_flat) whose result seeds the traversal's closest distance.
-    uint32_t flat_start[3], flat_count[3];   // indexed by PRIM_*
+    uint32_t flat_start[3], flat_count[3];   // record index of the first flat primitive of a type, how many
+    const float4 *tri_uv;    // 2 per triangle (by position among the triangles): (uv0.xy, uv1.xy) (uv2.xy, 0, 0)
+    const float4 *mats;      // 2 per material: (type bits, r, g, b) (emissive, roughness, ior, 0)
+    uint32_t nm;
     // textures, RGBA8, rows as uploaded
     const uchar4 *tex[2];
     uint32_t tex_w[2], tex_h[2];
