@@ -288,7 +288,7 @@ kl_status kl_create(kl_ctx **out, int32_t device, uint32_t width, uint32_t heigh
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->lc.cus = (uint32_t)prop.multiProcessorCount;
 #ifndef KL_ISECT_BLOCKS_PER_CU
-#define KL_ISECT_BLOCKS_PER_CU 5     // 4 waves x 8 KiB of traversal stack each -> five workgroups fill a CU's 160 KiB LDS
+#define KL_ISECT_BLOCKS_PER_CU 6     // 4 waves x (2.5 KiB stack + 4.1 KiB fetch staging) -> six workgroups share a CU's 160 KiB LDS
 #endif
     c->lc.isect_blocks_per_cu = KL_ISECT_BLOCKS_PER_CU;
     c->width = width; c->height = height;

@@ -97,9 +97,16 @@ __device__ __forceinline__ bool quad_intersect(v3 o, v3 d, v3 v0, v3 v1, v3 v2, 
 }
 // two-sided Moeller-Trumbore on (v0, e1, e2) with explicit fused multiply-adds (no reference counterpart)
 __device__ __forceinline__ bool tri_intersect(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float &t, float &bu, float &bv) {
+#ifdef KL_EXP_NOTRI
+    return false;
+#endif
     v3 p = fcross(d, e2);
     float det = fdot(e1, p);
+#ifdef KL_EXP_FASTRCP
+    float inv = __builtin_amdgcn_rcpf(det);
+#else
     float inv = 1.0f / det;
+#endif
     v3 s = o - v0;
     float u = fdot(s, p) * inv;
     if (!(u >= 0.0f && u <= 1.0f)) return false;
@@ -250,7 +257,7 @@ constexpr uint32_t ISECT_CHUNK = 256;        // rays a wave takes from the globa
 #define KL_ISECT_COOP 1            // quad-cooperative LDS-DMA record fetch (0: every lane loads its own record)
 #endif
 #ifndef KL_ISECT_LDS_STACK
-#define KL_ISECT_LDS_STACK 15      // stack entries per lane kept in LDS; 15 + the staging area lets five workgroups share a CU
+#define KL_ISECT_LDS_STACK 10      // stack entries per lane kept in LDS; 10 + the staging area lets six workgroups share a CU
 #endif
 constexpr uint32_t ISECT_REFILL = KL_ISECT_REFILL;   // refill idle lanes when fewer than this many are active
 
@@ -281,8 +288,11 @@ __device__ __forceinline__ void coop_fetch_one(const float4 *base, uint32_t my_o
     __builtin_amdgcn_global_load_lds((glb_void_t *)((const char *)base + off), (lds_void_t *)region, 16, 0, 0);
 }
 
+#ifndef KL_ISECT_MIN_WAVES
+#define KL_ISECT_MIN_WAVES 6       // waves per SIMD the register allocation must allow (<= 80 VGPRs)
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc, FrameDev f, RayQueue q, float4 *hits, uint32_t seeded,
+__global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_intersect_bvh(SceneDev sc, FrameDev f, RayQueue q, float4 *hits, uint32_t seeded,
                                                                    const uint32_t *counts, uint32_t *heads, Counters *cn, int *overflow) {
     __shared__ int stack[ISECT_WAVES][ISECT_LDS_STACK][64];
 #if KL_ISECT_COOP
@@ -369,9 +379,22 @@ __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc,
             coop_fetch_one<1>(sc.rec, my_offset, slice, regions + STAGE_REGION_F4);
             coop_fetch_one<2>(sc.rec, my_offset, slice, regions + 2 * STAGE_REGION_F4);
             coop_fetch_one<3>(sc.rec, my_offset, slice, regions + 3 * STAGE_REGION_F4);
+            // the entry a pop would return is read now, under the shadow of the record fetch: a step either
+            // pushes or pops, so it is still the top of the stack when the pop happens
+            int top = NODE_DONE;
+            if (active && sp > 0)
+                top = (uint32_t)(sp - 1) < ISECT_LDS_STACK ? st[(sp - 1) * 64] : ovf[((uint32_t)(sp - 1) - ISECT_LDS_STACK) * 64u];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const float4 *mine = &stage[wave_in_block][lane & 3u][(lane >> 2) * 4u];
             const float4 n0 = mine[0], n1 = mine[1], n2 = mine[2], n3 = mine[3];
+#endif
+#ifdef KL_EXP_EXTRA_VALU
+            {   // timing experiment only: N extra dependent VALU operations per step
+                float xx = n0.x;
+                #pragma unroll
+                for (int e = 0; e < KL_EXP_EXTRA_VALU; e++) xx = fmaf(xx, 1.0000001f, 0.5f);
+                asm volatile("" :: "v"(xx));
+            }
 #endif
             if (active) {
 #if !KL_ISECT_COOP
@@ -413,7 +436,11 @@ __global__ __launch_bounds__(64 * ISECT_WAVES) void k_intersect_bvh(SceneDev sc,
                 if (pop) {
                     if (sp > 0) {
                         sp--;
+#if KL_ISECT_COOP
+                        node = top;
+#else
                         node = (uint32_t)sp < ISECT_LDS_STACK ? st[sp * 64] : ovf[((uint32_t)sp - ISECT_LDS_STACK) * 64u];
+#endif
                     } else { hits[ray] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v); active = false; }
                 }
             }
@@ -473,7 +500,11 @@ __device__ __forceinline__ v3 tex_fetch(const SceneDev &sc, int which, float u, 
     float fx = floorf(u * (float)w), fy = floorf(v * (float)hgt);
     uint32_t ix = !(fx >= 0.0f) ? 0u : (fx >= (float)w ? w - 1u : (uint32_t)fx);
     uint32_t iy = !(fy >= 0.0f) ? 0u : (fy >= (float)hgt ? hgt - 1u : (uint32_t)fy);
+#ifdef KL_EXP_NOTEX
+    uchar4 px = make_uchar4((unsigned char)ix, (unsigned char)iy, 7, 255);   // timing experiment only
+#else
     uchar4 px = sc.tex[which][(size_t)iy * w + ix];
+#endif
     const float k = 1.0f / 255.0f;
     return V((float)px.x * k, (float)px.y * k, (float)px.z * k);
 }
@@ -614,7 +645,11 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
                 }
                 if (!done && bounce + 1 >= f.max_bounces) { done = true; col = V(0, 0, 0); }   // RF:406
             }
+#ifdef KL_EXP_NORAW
+            if (done && col.x == 12345.0f) raw[path] = make_float4(col.x, col.y, col.z, 1.0f);   // timing experiment only
+#else
             if (done) raw[path] = make_float4(col.x, col.y, col.z, 1.0f);
+#endif
             alive = !done;
         }
         if (fused) {

@@ -7,10 +7,8 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(k_\w+?)(ILb|ILi|E|$)", name)
-    base = m.group(1) if m else name
-    t = re.search(r"k_\w+?IL([bi])(\d)E", name)
-    return base + ("<%s>" % t.group(2) if t else "")
+    m = re.search(r"(k_\w+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:48]
 
 
 def main(path):
