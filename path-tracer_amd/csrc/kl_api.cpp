@@ -134,7 +134,7 @@ kl_status ensure_buffers(kl_ctx *c) {
         KL_HIP(c, hipMemsetAsync(c->d_acc.p, 0, c->npl * sizeof(float4), c->stream));
         KL_HIP(c, hipMemsetAsync(c->d_last_raw.p, 0, c->npl * sizeof(float4), c->stream));
     }
-    KL_HIP(c, c->d_qctl.alloc(2 * ((size_t)c->params.max_bounces + 2) * KL_QUEUE_SEGMENTS));
+    KL_HIP(c, c->d_qctl.alloc(2 * ((size_t)c->params.max_bounces + 2) * KL_QUEUE_SEGMENTS * CTR_STRIDE));
     if (!c->d_counters.p) {
         KL_HIP(c, c->d_counters.alloc(1));
         KL_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream));
@@ -213,14 +213,15 @@ kl_status render_batch(kl_ctx *c, uint32_t first, uint32_t nslots, bool camera_c
     FrameDev f = make_frame(c, first, nslots);
     const uint32_t B = c->params.max_bounces;
     // count[b] / head[b]: one word per queue segment and bounce
-    const uint32_t S = KL_QUEUE_SEGMENTS;
+    const size_t S = (size_t)KL_QUEUE_SEGMENTS * CTR_STRIDE;      // words per bounce level
     uint32_t *count = c->d_qctl.p, *head = c->d_qctl.p + (size_t)(B + 2) * S;
     const uint32_t max_rays = nslots * c->npl;
     RayQueue q[2] = { {c->d_od[0].p, c->d_d2[0].p, c->d_tp[0].p}, {c->d_od[1].p, c->d_d2[1].p, c->d_tp[1].p} };
     const bool fused = c->params.fused_compaction != 0;
-    KL_HIP(c, hipMemsetAsync(c->d_qctl.p, 0, c->d_qctl.n * sizeof(uint32_t), c->stream));
-    launch_generate(c->stream, c->lc, f, q[0], count);
     const uint32_t levels = c->mode == KL_MODE_PT ? B : (c->mode == KL_MODE_AO ? 2u : 1u);
+    KL_HIP(c, hipMemsetAsync(count, 0, (size_t)(levels + 1) * S * sizeof(uint32_t), c->stream));
+    KL_HIP(c, hipMemsetAsync(head, 0, (size_t)(levels + 1) * S * sizeof(uint32_t), c->stream));
+    launch_generate(c->stream, c->lc, f, q[0], count);
     for (uint32_t b = 0; b < levels; b++) {
         RayQueue qi = q[b & 1u], qo = q[(b + 1u) & 1u];
         kl_status s = timed_intersect(c, f, qi, count + (size_t)b * S, head + (size_t)b * S, max_rays);
@@ -603,7 +604,7 @@ kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, f
                      ~Cleanup() { a.release(); b.release(); c.release(); d.release(); e.release(); f.release(); g.release(); } }
         cleanup{b_od, b_hits, b_d2, b_uv, b_t, b_prim, b_ctl};
     KL_HIP(c, b_od.alloc(n)); KL_HIP(c, b_hits.alloc(n)); KL_HIP(c, b_d2.alloc(n)); KL_HIP(c, b_uv.alloc(n));
-    KL_HIP(c, b_t.alloc(n)); KL_HIP(c, b_prim.alloc(n)); KL_HIP(c, b_ctl.alloc(2));
+    KL_HIP(c, b_t.alloc(n)); KL_HIP(c, b_prim.alloc(n)); KL_HIP(c, b_ctl.alloc(2));   // one segment: count, head
     if (!c->d_counters.p) { KL_HIP(c, c->d_counters.alloc(1)); KL_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream)); }
     KL_HIP(c, c->d_overflow.alloc(intersect_overflow_ints(c->lc)));
     const uint32_t ctl[2] = { n, 0 };

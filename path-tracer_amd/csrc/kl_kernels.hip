@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_generate(FrameDev f, RayQueue q, uint32
             uint32_t ng = s < groups ? (groups - s + f.nseg - 1u) / f.nseg : 0u;
             uint32_t n = ng * 64u;
             if (ng && (groups - 1u) % f.nseg == s) n -= groups * 64u - total;   // the last group may be partial
-            count0[s] = n;
+            count0[s * CTR_STRIDE] = n;
         }
     }
     const float rx = (float)f.width, ry = (float)f.height;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_intersect_brute(SceneDev sc, FrameDev f
                                                          const uint32_t *counts, Counters *cn) {
     // block b works on segment b % nseg together with the other blocks of that residue
     const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
-    const uint32_t count = counts[seg];
+    const uint32_t count = counts[seg * CTR_STRIDE];
     if (sub == 0 && threadIdx.x == 0 && count) atomicAdd(&cn->rays, (unsigned long long)count);
     for (uint32_t r = sub * blockDim.x + threadIdx.x; r < count; r += nsub * blockDim.x) {
         const uint32_t i = seg * f.segcap + r;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_intersect_brute(SceneDev sc, FrameDev f
 __global__ __launch_bounds__(256) void k_intersect_flat(SceneDev sc, FrameDev f, RayQueue q, float4 *hits,
                                                         const uint32_t *counts, Counters *cn, uint32_t stats) {
     const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
-    const uint32_t count = counts[seg];
+    const uint32_t count = counts[seg * CTR_STRIDE];
     if (stats && sub == 0 && threadIdx.x == 0 && count) {
         atomicAdd(&cn->sphere_tests, (unsigned long long)count * sc.flat_count[PRIM_SPHERE]);
         atomicAdd(&cn->quad_tests, (unsigned long long)count * sc.flat_count[PRIM_QUAD]);
@@ -304,8 +304,8 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
     int *ovf = overflow + ((size_t)(blockIdx.x * ISECT_WAVES + wave_in_block) * ISECT_OVF_STACK) * 64u + lane;
     // this workgroup serves queue segment blockIdx % nseg; its waves pull ray chunks from that segment's head
     const uint32_t seg = blockIdx.x % f.nseg;
-    const uint32_t count = counts[seg];
-    uint32_t *head = heads + seg;
+    const uint32_t count = counts[seg * CTR_STRIDE];
+    uint32_t *head = heads + seg * CTR_STRIDE;
     const uint32_t seg_base = seg * f.segcap;
     if (blockIdx.x < f.nseg && threadIdx.x == 0 && count) atomicAdd(&cn->rays, (unsigned long long)count);
 
@@ -557,8 +557,8 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
                                                float4 *raw, uint32_t bounce, uint32_t fused) {
     // block b works on segment b % nseg; survivors stay in their segment
     const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
-    const uint32_t count = counts_in[seg];
-    uint32_t *count_out = counts_out + seg;
+    const uint32_t count = counts_in[seg * CTR_STRIDE];
+    uint32_t *count_out = counts_out + seg * CTR_STRIDE;
     const uint32_t seg_base = seg * f.segcap;
     const uint32_t nwaves = (nsub * blockDim.x) >> 6;
     const uint32_t wave = (sub * blockDim.x + threadIdx.x) >> 6;
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
 // stream compaction of a shaded queue: ballot + popcount, one atomic per wave
 __global__ __launch_bounds__(256) void k_compact(FrameDev f, RayQueue qin, const uint32_t *counts_in, RayQueue qout, uint32_t *counts_out) {
     const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
-    const uint32_t count = counts_in[seg];
+    const uint32_t count = counts_in[seg * CTR_STRIDE];
     const uint32_t seg_base = seg * f.segcap;
     const uint32_t nwaves = (nsub * blockDim.x) >> 6;
     const uint32_t wave = (sub * blockDim.x + threadIdx.x) >> 6;
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void k_compact(FrameDev f, RayQueue qin, const
         float4 tp = make_float4(0, 0, 0, 0);
         bool alive = false;
         if (base + lane_id() < count) { tp = qin.tp[i]; alive = __float_as_uint(tp.w) != PATH_DEAD; }
-        uint32_t dst = seg_base + wave_reserve(counts_out + seg, alive);
+        uint32_t dst = seg_base + wave_reserve(counts_out + seg * CTR_STRIDE, alive);
         if (alive) { qout.od[dst] = qin.od[i]; qout.d2[dst] = qin.d2[i]; qout.tp[dst] = tp; }
     }
 }

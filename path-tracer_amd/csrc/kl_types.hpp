@@ -82,6 +82,9 @@ struct FrameDev {
 // atomics of compaction spread over nseg words instead of one. generate deals 64-path groups
 // round-robin over the segments; a survivor always stays in its segment, hence a segment never
 // holds more than it started with and segcap = ceil(paths / nseg) is enough at every bounce.
+// The per-segment counters are CTR_STRIDE words apart (256 bytes): memory-side atomics on words of one
+// cache line serialise as if they hit one word, so neighbouring segments must not share a line.
+constexpr uint32_t CTR_STRIDE = 64;
 struct RayQueue {
     float4 *od;
     float2 *d2;
