@@ -61,7 +61,7 @@ struct kl_ctx {
     uint32_t n_prims = 0;
     SceneDev sc;
     kl_bvh_stats bvh_stats;
-    DevBuf<float4> d_rec, d_tri_uv, d_mats;
+    DevBuf<float4> d_rec, d_tri_uv, d_mats, d_flatq;
     DevBuf<uchar4> d_tex[2];
     // wavefront state
     uint32_t slots = 0;               // frames in flight the buffers are sized for
@@ -314,7 +314,7 @@ kl_status kl_destroy(kl_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (const EventPair &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
-    c->d_rec.release(); c->d_tri_uv.release(); c->d_mats.release();
+    c->d_rec.release(); c->d_tri_uv.release(); c->d_mats.release(); c->d_flatq.release();
     for (int k = 0; k < 2; k++) { c->d_tex[k].release(); c->d_od[k].release(); c->d_d2[k].release(); c->d_tp[k].release(); }
     c->d_hits.release(); c->d_raw.release(); c->d_acc.release(); c->d_last_raw.release();
     c->d_qctl.release(); c->d_counters.release(); c->d_resolve.release(); c->d_overflow.release();
@@ -450,13 +450,36 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
         mats[2 * (size_t)k] = make_float4(tf, m[k].color[0], m[k].color[1], m[k].color[2]);
         mats[2 * (size_t)k + 1] = make_float4(m[k].emissive, m[k].roughness, m[k].ior, 0.0f);
     }
+    // ray-independent terms of the quad test (RawFrame.glsl:219-244) for the flat quads, in the test's own operations
+    const uint32_t nfq = bvh.flat_count[PRIM_QUAD];
+    std::vector<float4> flatq((size_t)nfq * 5);
+    for (uint32_t k = 0; k < nfq; k++) {
+        const uint32_t qi = bvh.quad_order[bvh.flat_start[PRIM_QUAD] + k];
+        const kl_quad &x = q[qi];
+        v3 v0 = V(x.v0[0], x.v0[1], x.v0[2]);
+        v3 a = V(x.v1[0], x.v1[1], x.v1[2]) - v0, b = V(x.v3[0], x.v3[1], x.v3[2]) - v0, cc = V(x.v2[0], x.v2[1], x.v2[2]) - v0;
+        v3 nor = cross(a, b);
+        v3 mor = V(std::fabs(nor.x), std::fabs(nor.y), std::fabs(nor.z));
+        int id = (mor.x > mor.y && mor.x > mor.z) ? 0 : ((mor.y > mor.z) ? 1 : 2);
+        int idu = id == 0 ? 1 : (id == 1 ? 2 : 0), idv = id == 0 ? 2 : (id == 1 ? 0 : 1);
+        float kax = comp(a, idu), kay = comp(a, idv), kbx = comp(b, idu), kby = comp(b, idv);
+        float kcx = comp(cc, idu), kcy = comp(cc, idv);
+        float kgx = kcx - kbx - kax, kgy = kcy - kby - kay;
+        float k2 = cross2d(kcx - kbx, kcy - kby, kax, kay);
+        flatq[5 * (size_t)k] = make_float4(v0.x, v0.y, v0.z, comp(nor, id));
+        flatq[5 * (size_t)k + 1] = make_float4(nor.x, nor.y, nor.z, k2);
+        flatq[5 * (size_t)k + 2] = make_float4(kax, kay, kbx, kby);
+        flatq[5 * (size_t)k + 3] = make_float4(kgx, kgy, bits((uint32_t)idu | ((uint32_t)idv << 2)), 0.0f);
+        flatq[5 * (size_t)k + 4] = make_float4(bits(ns + qi), 0.0f, 0.0f, 0.0f);
+    }
     kl_status st;
+    if ((st = upload(c, c->d_flatq, flatq.data(), flatq.size())) != KL_OK) return st;
     if ((st = upload(c, c->d_rec, rec.data(), rec.size())) != KL_OK) return st;
     if ((st = upload(c, c->d_tri_uv, tuv.data(), tuv.size())) != KL_OK) return st;
     if ((st = upload(c, c->d_mats, mats.data(), mats.size())) != KL_OK) return st;
     KL_HIP(c, hipStreamSynchronize(c->stream));     // the host vectors go out of scope below
     c->sc.rec = c->d_rec.p; c->sc.root = patch_child(bvh.root); c->sc.n_nodes = n_nodes;
-    c->sc.tri_uv = c->d_tri_uv.p; c->sc.mats = c->d_mats.p; c->sc.nm = nm;
+    c->sc.tri_uv = c->d_tri_uv.p; c->sc.mats = c->d_mats.p; c->sc.nm = nm; c->sc.flatq = c->d_flatq.p;
     c->sc.count[PRIM_SPHERE] = ns; c->sc.count[PRIM_QUAD] = nq; c->sc.count[PRIM_TRI] = nt;
     for (int k = 0; k < 3; k++) {
         c->sc.base[k] = base[k];

@@ -214,6 +214,43 @@ __global__ __launch_bounds__(256) void k_intersect_brute(SceneDev sc, FrameDev f
 }
 
 // ------------------------------------------------------------------ intersect: flat primitives
+// Flat quads: the quad test of RF:218-269 with its ray-independent terms (nor, ka, kb, kg, k2, projection
+// axes) taken precomputed from upload, where they were evaluated with the same operations. All lanes walk the
+// same quad, so every table value is a uniform (scalar) load and the axis selects cost nothing.
+__device__ __forceinline__ void flat_quads(const SceneDev &sc, v3 o, v3 d, Hit &h) {
+    const uint32_t nq = sc.flat_count[PRIM_QUAD];
+    for (uint32_t k = 0; k < nq; k++) {
+        const float4 F0 = sc.flatq[5 * k], F1 = sc.flatq[5 * k + 1], F2 = sc.flatq[5 * k + 2], F3 = sc.flatq[5 * k + 3];
+        const uint32_t id = __float_as_uint(sc.flatq[5 * k + 4].x);
+        const v3 p = o - V(F0.x, F0.y, F0.z), nor = V(F1.x, F1.y, F1.z);
+        const float t = -dot(p, nor) / dot(d, nor);                  // RF:225
+        if (t < 0.0f) continue;                                      // RF:226
+        if (!(t > 0.001f && t <= h.t)) continue;                     // cannot pass RF:316 whatever (u, v) are
+        const v3 pos = p + d * t;
+        const uint32_t axes = __float_as_uint(F3.z);
+        const int idu = (int)(axes & 3u), idv = (int)((axes >> 2) & 3u);
+        const float kpx = comp(pos, idu), kpy = comp(pos, idv);
+        const float kax = F2.x, kay = F2.y, kbx = F2.z, kby = F2.w, kgx = F3.x, kgy = F3.y, k2 = F1.w;
+        const float k0 = cross2d(kpx, kpy, kbx, kby);
+        const float k1 = cross2d(kpx, kpy, kgx, kgy) - F0.w;
+        float u, v;
+        if (fabsf(k2) < 0.00001f) {
+            v = -k0 / k1;
+            u = cross2d(kpx, kpy, kax, kay) / k1;
+        } else {
+            float w = k1 * k1 - 4.0f * k0 * k2;
+            if (w < 0.0f) continue;
+            w = sqrtf(w);
+            float ik2 = 1.0f / (2.0f * k2);
+            v = (-k1 - w) * ik2;
+            if (v < 0.0f || v > 1.0f) v = (-k1 + w) * ik2;
+            u = (kpx - kax * v) / (kbx + kgx * v);
+        }
+        if (u < 0.0f || u > 1.0f || v < 0.0f || v > 1.0f) continue;
+        accept(h, t, make_ref(PRIM_QUAD, sc.flat_start[PRIM_QUAD] + k), id, v, 1.0f - u);
+    }
+}
+
 // The few scene-spanning primitives kept out of the tree, tested for every ray in queue order (uniform
 // loads, no divergence). Writes the hit record that k_intersect_bvh then starts from, so the traversal
 // begins with the ray already clipped by the walls.
@@ -233,7 +270,7 @@ __global__ __launch_bounds__(256) void k_intersect_flat(SceneDev sc, FrameDev f,
         Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
         if (ray_finite(o, d)) {
             test_range(sc, PRIM_SPHERE, sc.flat_start[PRIM_SPHERE], sc.flat_count[PRIM_SPHERE], o, d, f.eps, h);
-            test_range(sc, PRIM_QUAD, sc.flat_start[PRIM_QUAD], sc.flat_count[PRIM_QUAD], o, d, f.eps, h);
+            flat_quads(sc, o, d, h);
             test_range(sc, PRIM_TRI, sc.flat_start[PRIM_TRI], sc.flat_count[PRIM_TRI], o, d, f.eps, h);
         }
         hits[i] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);

@@ -51,6 +51,9 @@ struct SceneDev {
     // out of the tree, sit at the end of their type's records, and are tested for every ray by a coherent
     // pass (k_intersect_flat) whose result seeds the traversal's closest distance.
     uint32_t flat_start[3], flat_count[3];   // record index of the first flat primitive of a type, how many
+    // per flat quad, the ray-independent part of the quad test evaluated once at upload (5 float4 each):
+    //   F0 = (v0.xyz, nor[id])  F1 = (nor.xyz, k2)  F2 = (ka.xy, kb.xy)  F3 = (kg.xy, idu | idv << 2, 0)  F4 = (id bits, 0, 0, 0)
+    const float4 *flatq;
     const float4 *tri_uv;    // 2 per triangle (by position among the triangles): (uv0.xy, uv1.xy) (uv2.xy, 0, 0)
     const float4 *mats;      // 2 per material: (type bits, r, g, b) (emissive, roughness, ior, 0)
     uint32_t nm;
