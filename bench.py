@@ -148,8 +148,12 @@ def main():
     cs = r.counters()
     r.update_params(collect_stats=0)
     rays_stat = max(cs.rays, 1)
-    n_node, n_tri = cs.nodes / rays_stat, cs.tri_tests / rays_stat
-    n_sph, n_quad = cs.sphere_tests / rays_stat, cs.quad_tests / rays_stat
+    # per ray: nodes visited and primitives tested INSIDE the traversal kernel. The flat primitives (room
+    # walls: tested for every ray by the separate coherent pass, through uniform loads) are not part of it.
+    n_node = cs.nodes / rays_stat
+    n_tri = cs.tri_tests / rays_stat - bvh.flat_tris
+    n_sph = cs.sphere_tests / rays_stat - bvh.flat_spheres
+    n_quad = cs.quad_tests / rays_stat - bvh.flat_quads
     b_ray = 64.0 * n_node + 48.0 * n_tri + 16.0 * n_sph + 48.0 * n_quad + QUEUE_BYTES_PER_RAY
     lane_active = cs.lane_steps_active / max(cs.lane_steps_total, 1)
 
@@ -193,13 +197,16 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_intersect_launch")
+                traffic = json.load(open(tpath)).get("fabric_bytes_per_intersect_launch")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "k_intersect_bvh", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(n_node, 2), "tris_per_ray": round(n_tri, 2),
                     "spheres_per_ray": round(n_sph, 3), "quads_per_ray": round(n_quad, 3),
+                    "flat_prims_per_ray": int(bvh.flat_spheres + bvh.flat_quads + bvh.flat_tris),
+                    "note": "algorithmic bytes (SURVEY 8d formula) / HIP-event time of k_intersect_bvh; BVH+triangles (83 MB) live in "
+                            "L2/Infinity Cache, so this figure may exceed the HBM peak: `traffic` is what actually crossed the fabric",
                     "rays_per_launch": round(rays_rank / tm.intersect_launches, 1),
                     "launches": int(tm.intersect_launches), "avg_launch_ms": round(tm.intersect_ms / tm.intersect_launches, 4),
                     "intersect_share_of_step": round(isect_s / elapsed, 3), "lane_active_frac": round(lane_active, 3),

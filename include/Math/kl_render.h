@@ -116,6 +116,8 @@ typedef struct kl_bvh_stats {
     float sah_cost;
     double build_seconds;
     uint64_t node_bytes, prim_bytes;
+    uint32_t flat_spheres, flat_quads, flat_tris; /* scene-spanning primitives kept out of the tree and tested for every ray */
+    uint32_t reserved;
 } kl_bvh_stats;
 
 /* parameters of the seed-deterministic synthetic benchmark scene */
@@ -188,7 +190,7 @@ KL_API kl_status kl_trace_rays(kl_ctx *ctx, const float *o, const float *d, uint
 
 /* -- partitioning over GPUs (no reference counterpart). Image tiles: this context renders the
  *    row bands b with b % world == rank, band_rows rows each; its buffers then hold only those
- *    rows, top band first. Sample ranges: use KL_ACCUM_SUM and disjoint first_frame ranges. -- */
+ *    rows, in increasing row order. Sample ranges: use KL_ACCUM_SUM and disjoint first_frame ranges. -- */
 KL_API kl_status kl_set_shard(kl_ctx *ctx, uint32_t rank, uint32_t world, uint32_t band_rows);
 KL_API kl_status kl_get_local_rows(kl_ctx *ctx, uint32_t *rows);
 KL_API kl_status kl_set_accum_mode(kl_ctx *ctx, uint32_t mode);

@@ -197,12 +197,16 @@ bool use_bvh(const kl_ctx *c) {
 
 kl_status timed_intersect(kl_ctx *c, const FrameDev &f, RayQueue q, uint32_t *count, uint32_t *head, uint32_t max_rays) {
     hipEvent_t a = nullptr, b = nullptr;
+    const bool bvh = use_bvh(c);
+    if (bvh && scene_has_flat(c->sc))
+        launch_intersect_flat(c->stream, c->lc, c->sc, f, q, c->d_hits.p, count, c->d_counters.p, c->params.collect_stats != 0, max_rays);
+    // the events bracket the dominant kernel only (k_intersect_bvh, or the flat loop for small scenes)
     if (c->params.profile_kernels) {
         if (c->pending.size() >= KL_MAX_PENDING_EVENTS) drain_events(c);
         a = get_event(c); b = get_event(c);
         if (a && b) KL_HIP(c, hipEventRecord(a, c->stream));
     }
-    launch_intersect(c->stream, c->lc, c->sc, f, q, c->d_hits.p, count, head, c->d_counters.p, c->d_overflow.p, use_bvh(c),
+    launch_intersect(c->stream, c->lc, c->sc, f, q, c->d_hits.p, count, head, c->d_counters.p, c->d_overflow.p, bvh,
                      c->params.collect_stats != 0, max_rays);
     if (a && b) { KL_HIP(c, hipEventRecord(b, c->stream)); c->pending.push_back({a, b, 0}); }
     return KL_OK;
@@ -488,6 +492,8 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     c->n_prims = ns + nq + nt;
     c->bvh_stats = bvh.stats;
     c->bvh_stats.prim_bytes = ((uint64_t)ns + nq + nt) * 64;
+    c->bvh_stats.flat_spheres = bvh.flat_count[PRIM_SPHERE]; c->bvh_stats.flat_quads = bvh.flat_count[PRIM_QUAD];
+    c->bvh_stats.flat_tris = bvh.flat_count[PRIM_TRI]; c->bvh_stats.reserved = 0;
     c->have_scene = true;
     return kl_reset(c);
 }
@@ -637,6 +643,8 @@ kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, f
     FrameDev f = make_frame(c, 0, 1);
     f.nseg = 1; f.segcap = n;                       // caller rays form one segment
     RayQueue q = { b_od.p, b_d2.p, nullptr };
+    if (use_bvh(c) && scene_has_flat(c->sc))
+        launch_intersect_flat(c->stream, c->lc, c->sc, f, q, b_hits.p, &b_ctl.p[0], c->d_counters.p, c->params.collect_stats != 0, n);
     launch_intersect(c->stream, c->lc, c->sc, f, q, b_hits.p, &b_ctl.p[0], &b_ctl.p[1], c->d_counters.p, c->d_overflow.p, use_bvh(c),
                      c->params.collect_stats != 0, n);
     launch_unpack_hits(c->stream, c->sc, b_hits.p, n, b_t.p, b_prim.p, b_uv.p);

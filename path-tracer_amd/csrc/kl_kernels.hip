@@ -809,15 +809,19 @@ void launch_generate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQ
 size_t intersect_overflow_ints(const LaunchCfg &lc) {
     return (size_t)lc.cus * lc.isect_blocks_per_cu * ISECT_WAVES * ISECT_OVF_STACK * 64u;
 }
+bool scene_has_flat(const SceneDev &sc) { return (sc.flat_count[0] + sc.flat_count[1] + sc.flat_count[2]) != 0u; }
+// the coherent pass over the flat primitives; precedes launch_intersect when the tree is used and scene_has_flat()
+void launch_intersect_flat(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q, float4 *hits,
+                           const uint32_t *counts, Counters *cn, bool stats, uint32_t max_rays) {
+    hipLaunchKernelGGL(k_intersect_flat, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, hits, counts, cn, stats ? 1u : 0u);
+}
 void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q, float4 *hits,
                       const uint32_t *counts, uint32_t *heads, Counters *cn, int *overflow, bool bvh, bool stats, uint32_t max_rays) {
     if (!bvh) {
         hipLaunchKernelGGL(k_intersect_brute, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, hits, counts, cn);
         return;
     }
-    const uint32_t seeded = (sc.flat_count[0] + sc.flat_count[1] + sc.flat_count[2]) ? 1u : 0u;
-    if (seeded)
-        hipLaunchKernelGGL(k_intersect_flat, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, hits, counts, cn, stats ? 1u : 0u);
+    const uint32_t seeded = scene_has_flat(sc) ? 1u : 0u;
     uint32_t blocks = seg_grid(f, max_rays, lc.cus * lc.isect_blocks_per_cu, ISECT_CHUNK * ISECT_WAVES);
     if (stats) hipLaunchKernelGGL(k_intersect_bvh<true>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, seeded, counts, heads, cn, overflow);
     else hipLaunchKernelGGL(k_intersect_bvh<false>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, seeded, counts, heads, cn, overflow);

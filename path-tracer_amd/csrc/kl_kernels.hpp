@@ -14,6 +14,9 @@ struct LaunchCfg {
 void launch_generate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue q, uint32_t *count0);
 // ints of global memory the traversal kernel needs for stack entries beyond its LDS part (per launch grid)
 size_t intersect_overflow_ints(const LaunchCfg &lc);
+bool scene_has_flat(const SceneDev &sc);
+void launch_intersect_flat(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q, float4 *hits,
+                           const uint32_t *counts, Counters *cn, bool stats, uint32_t max_rays);
 void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q, float4 *hits,
                       const uint32_t *count, uint32_t *head, Counters *cn, int *overflow, bool bvh, bool stats, uint32_t max_rays);
 void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin, const float4 *hits,

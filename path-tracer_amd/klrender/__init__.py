@@ -57,7 +57,8 @@ class Timing(C.Structure):
 class BvhStats(C.Structure):
     _fields_ = [("nodes", C.c_uint32), ("leaves", C.c_uint32), ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32),
                 ("spheres", C.c_uint32), ("quads", C.c_uint32), ("tris", C.c_uint32), ("sah_cost", C.c_float),
-                ("build_seconds", C.c_double), ("node_bytes", C.c_uint64), ("prim_bytes", C.c_uint64)]
+                ("build_seconds", C.c_double), ("node_bytes", C.c_uint64), ("prim_bytes", C.c_uint64),
+                ("flat_spheres", C.c_uint32), ("flat_quads", C.c_uint32), ("flat_tris", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class SynthParams(C.Structure):
