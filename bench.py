@@ -55,25 +55,19 @@ def cpu_baseline(scene_arrays, textures, width, height, bounces, budget_s):
     sc.set_texture(ko.TEX_ALBEDO, textures[1])
     p = ko.default_params(width=width, height=height, mode=ko.MODE_PT, max_frames=0, max_bounces=bounces, use_bvh=1)
     cam = ko.default_camera()
-    mid = height // 2
+    # one untimed row band to page the scene in, then whole frames until the time budget is used
+    sc.render_raw(cam, p, 0, rows=(height // 2, height // 2 + 8), nthreads=threads)
     cn = ko.Counters()
     t0 = time.perf_counter()
-    sc.render_raw(cam, p, 0, rows=(mid, mid + 8), nthreads=threads, counters=cn)       # calibration
-    dt = max(time.perf_counter() - t0, 1e-3)
-    rows_budget = max(8.0, 8 * budget_s / dt)
-    cn = ko.Counters()
-    t0 = time.perf_counter()
-    if rows_budget <= height:
-        rows = int(rows_budget)
-        y0 = max(0, mid - rows // 2)
-        sc.render_raw(cam, p, 0, rows=(y0, y0 + rows), nthreads=threads, counters=cn)
-        what = "rows %d..%d of frame 0" % (y0, y0 + rows - 1)
-    else:
-        nframes = int(min(64, max(1, rows_budget // height)))
-        for f in range(nframes):
-            sc.render_raw(cam, p, f, nthreads=threads, counters=cn)
-        what = "frames 0..%d (all rows)" % (nframes - 1)
+    nframes = 0
+    while nframes < 64:
+        sc.render_raw(cam, p, nframes, nthreads=threads, counters=cn)
+        nframes += 1
+        dt = time.perf_counter() - t0
+        if dt + dt / nframes > budget_s:
+            break
     dt = time.perf_counter() - t0
+    what = "frames 0..%d (all rows)" % (nframes - 1)
     return {"value": cn.paths / dt, "unit": "samples/s", "cores": threads, "kind": "port",
             "mrays_per_s": cn.rays / dt / 1e6, "seconds": round(dt, 2),
             "sample": "%s of the same %dx%d %d-bounce workload (%d paths, %d rays), oracle C port with its own median-split BVH, %d OpenMP threads"

@@ -163,6 +163,75 @@ void pad_box(Box &b) {
 
 }  // namespace
 
+namespace {
+struct Child4 { Box box; int32_t ref; };
+
+uint32_t collapse_node(const HostBVH &bvh, int32_t node2, std::vector<uint32_t> &out, uint32_t depth, uint32_t &max_depth) {
+    auto child_of = [&](int32_t n2, int k) {
+        const float *o = &bvh.nodes[(size_t)n2 * 16];
+        Child4 c;
+        for (int a = 0; a < 3; a++) { c.box.lo[a] = o[6 * k + a]; c.box.hi[a] = o[6 * k + 3 + a]; }
+        std::memcpy(&c.ref, o + 12 + k, 4);
+        return c;
+    };
+    std::vector<Child4> ch = { child_of(node2, 0), child_of(node2, 1) };
+    while (ch.size() < 4) {            // open the inner child with the largest box
+        int best = -1; float best_area = -1.0f;
+        for (size_t i = 0; i < ch.size(); i++)
+            if (ch[i].ref >= 0 && ch[i].box.area() > best_area) { best = (int)i; best_area = ch[i].box.area(); }
+        if (best < 0) break;
+        int32_t open = ch[best].ref;
+        ch[best] = child_of(open, 0);
+        ch.push_back(child_of(open, 1));
+    }
+    max_depth = std::max(max_depth, depth);
+    const uint32_t idx = (uint32_t)(out.size() / 16);
+    out.resize(out.size() + 16, 0u);
+    Box nb; nb.reset();
+    for (const Child4 &c : ch) nb.grow(c.box);
+    uint32_t w[16]; std::memset(w, 0, sizeof w);
+    uint32_t ebyte[3]; double scale[3];
+    for (int a = 0; a < 3; a++) {
+        std::memcpy(&w[a], &nb.lo[a], 4);
+        double ext = (double)nb.hi[a] - (double)nb.lo[a];
+        int e = ext > 0.0 ? (int)std::ceil(std::log2(ext / 255.0)) : -100;
+        if (e < -100) e = -100;
+        while (std::ldexp(255.0, e) < ext) e++;          // guard the rounding of log2
+        ebyte[a] = (uint32_t)(e + 127);
+        scale[a] = std::ldexp(1.0, e);
+    }
+    w[3] = ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16);
+    for (int k = 0; k < 4; k++) {
+        uint32_t qlo[3] = {255, 255, 255}, qhi[3] = {0, 0, 0};     // empty slot: inverted box, never entered
+        if (k < (int)ch.size()) {
+            for (int a = 0; a < 3; a++) {
+                double l = std::floor(((double)ch[k].box.lo[a] - (double)nb.lo[a]) / scale[a]);
+                double h = std::ceil(((double)ch[k].box.hi[a] - (double)nb.lo[a]) / scale[a]);
+                qlo[a] = (uint32_t)std::min(255.0, std::max(0.0, l));
+                qhi[a] = (uint32_t)std::min(255.0, std::max(0.0, h));
+            }
+        }
+        for (int a = 0; a < 3; a++) { w[4 + a] |= qlo[a] << (8 * k); w[7 + a] |= qhi[a] << (8 * k); }
+    }
+    for (int k = 0; k < 4; k++) {
+        int32_t ref = NODE_DONE;
+        if (k < (int)ch.size()) ref = ch[k].ref >= 0 ? (int32_t)collapse_node(bvh, ch[k].ref, out, depth + 1, max_depth) : ch[k].ref;
+        std::memcpy(&w[10 + k], &ref, 4);
+    }
+    std::memcpy(&out[(size_t)idx * 16], w, sizeof w);
+    return idx;
+}
+}  // namespace
+
+void collapse_bvh4(HostBVH &bvh) {
+    bvh.nodes4.clear(); bvh.depth4 = 0;
+    bvh.root4 = bvh.root;                       // an empty tree or a lone leaf stays what it is
+    if (bvh.root >= 0 && bvh.root != NODE_DONE) {
+        bvh.nodes4.reserve(bvh.nodes.size() / 2);
+        bvh.root4 = (int32_t)collapse_node(bvh, bvh.root, bvh.nodes4, 1, bvh.depth4);
+    }
+}
+
 void identity_order(uint32_t ns, uint32_t nq, uint32_t nt, HostBVH &out) {
     out.nodes.clear(); out.root = NODE_DONE;
     out.sph_order.resize(ns); out.quad_order.resize(nq); out.tri_order.resize(nt);

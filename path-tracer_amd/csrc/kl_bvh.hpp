@@ -18,6 +18,10 @@ struct HostBVH {
     std::vector<uint32_t> tri_order;
     uint32_t flat_start[3], flat_count[3];   // flat primitives close each order array (indexed by PRIM_*)
     kl_bvh_stats stats;
+    // 4-wide form of the same tree (collapse_bvh4): 16 words (64 bytes) per node, see kl_types.hpp
+    std::vector<uint32_t> nodes4;
+    int32_t root4;
+    uint32_t depth4;
 };
 
 // Builds over all primitives. Guarantees: every leaf holds 1..8 primitives of one type; no leaf
@@ -30,6 +34,11 @@ struct HostBVH {
 // in divergent leaves. flat_fraction <= 0 disables this.
 void build_bvh(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
                HostBVH &out, unsigned threads, float flat_fraction, uint32_t max_flat);
+
+// Collapses the binary tree into 4-wide nodes with 8-bit child boxes quantised outwards on the node's own
+// grid (64 bytes per node). Leaves and their order are untouched; boxes only get looser, never tighter, so
+// traversal visits a superset of what the exact boxes admit and finds the same hits.
+void collapse_bvh4(HostBVH &bvh);
 
 // No tree: identity ordering, root = NODE_DONE (flat-loop kernel only).
 void identity_order(uint32_t ns, uint32_t nq, uint32_t nt, HostBVH &out);

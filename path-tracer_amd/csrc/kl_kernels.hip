@@ -312,7 +312,9 @@ constexpr uint32_t ISECT_REFILL = KL_ISECT_REFILL;   // refill idle lanes when f
 // Stack. The first ISECT_LDS_STACK entries of a lane's traversal stack live in LDS ([wave][entry][lane]:
 // consecutive lanes on consecutive banks); deeper entries (rare) spill to a per-wave slab in global memory.
 constexpr uint32_t ISECT_LDS_STACK = KL_ISECT_LDS_STACK;
-constexpr uint32_t ISECT_OVF_STACK = BVH_MAX_DEPTH > ISECT_LDS_STACK ? BVH_MAX_DEPTH - ISECT_LDS_STACK : 1;
+// a binary step pushes at most one entry per level, a 4-wide step at most three
+constexpr uint32_t ISECT_STACK_MAX = KL_BVH4 ? 3u * BVH_MAX_DEPTH : (uint32_t)BVH_MAX_DEPTH;
+constexpr uint32_t ISECT_OVF_STACK = ISECT_STACK_MAX > ISECT_LDS_STACK ? ISECT_STACK_MAX - ISECT_LDS_STACK : 1;
 constexpr uint32_t STAGE_REGION_F4 = 65;      // 64 float4 (1 KiB) of payload + 16 bytes of skew per region
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -439,8 +441,54 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                 const float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
 #endif
                 bool pop = false;
+                auto push = [&](int ref) {
+                    if ((uint32_t)sp < ISECT_LDS_STACK) st[sp * 64] = ref;
+                    else ovf[((uint32_t)sp - ISECT_LDS_STACK) * 64u] = ref;
+                    sp++;
+                };
                 if (inner) {
                     if (STATS) s_nodes++;
+#if KL_BVH4
+                    // four child boxes on the node's 8-bit grid: plane = lo + byte * step, so along the ray
+                    // t = byte * (step * 1/d) + (lo - o) * 1/d; near and far planes are picked by the sign of 1/d
+                    const uint32_t ew = __float_as_uint(n0.w);
+                    const float Ax = __uint_as_float((ew & 0xFFu) << 23) * id.x;
+                    const float Ay = __uint_as_float(((ew >> 8) & 0xFFu) << 23) * id.y;
+                    const float Az = __uint_as_float(((ew >> 16) & 0xFFu) << 23) * id.z;
+                    const float Bx = fmaf(n0.x, id.x, nood.x), By = fmaf(n0.y, id.y, nood.y), Bz = fmaf(n0.z, id.z, nood.z);
+                    const uint32_t lox = __float_as_uint(n1.x), loy = __float_as_uint(n1.y), loz = __float_as_uint(n1.z);
+                    const uint32_t hix = __float_as_uint(n1.w), hiy = __float_as_uint(n2.x), hiz = __float_as_uint(n2.y);
+                    const bool px = id.x >= 0.0f, py = id.y >= 0.0f, pz = id.z >= 0.0f;
+                    const uint32_t nx = px ? lox : hix, fx = px ? hix : lox;
+                    const uint32_t ny = py ? loy : hiy, fy = py ? hiy : loy;
+                    const uint32_t nz = pz ? loz : hiz, fz = pz ? hiz : loz;
+                    int ref[4] = { __float_as_int(n2.z), __float_as_int(n2.w), __float_as_int(n3.x), __float_as_int(n3.y) };
+                    float key[4];
+                    const float inf = __builtin_huge_valf();
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float tnx = fmaf((float)((nx >> (8 * k)) & 0xFFu), Ax, Bx), tfx = fmaf((float)((fx >> (8 * k)) & 0xFFu), Ax, Bx);
+                        const float tny = fmaf((float)((ny >> (8 * k)) & 0xFFu), Ay, By), tfy = fmaf((float)((fy >> (8 * k)) & 0xFFu), Ay, By);
+                        const float tnz = fmaf((float)((nz >> (8 * k)) & 0xFFu), Az, Bz), tfz = fmaf((float)((fz >> (8 * k)) & 0xFFu), Az, Bz);
+                        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+                        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, h.t));
+                        key[k] = (tn <= tf && ref[k] != NODE_DONE) ? tn : inf;
+                    }
+                    // sort the four (entry distance, child) pairs, nearest first
+                    auto cswap = [&](int a, int b) {
+                        const bool sw = key[b] < key[a];
+                        const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];
+                        const int ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];
+                        key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb;
+                    };
+                    cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+                    if (key[0] < inf) {
+                        if (key[3] < inf) push(ref[3]);      // farthest first, so the nearest pending child pops first
+                        if (key[2] < inf) push(ref[2]);
+                        if (key[1] < inf) push(ref[1]);
+                        node = ref[0];
+                    } else pop = true;
+#else
                     float ax0 = fmaf(n0.x, id.x, nood.x), ax1 = fmaf(n0.w, id.x, nood.x);
                     float ay0 = fmaf(n0.y, id.y, nood.y), ay1 = fmaf(n1.x, id.y, nood.y);
                     float az0 = fmaf(n0.z, id.z, nood.z), az1 = fmaf(n1.y, id.z, nood.z);
@@ -456,13 +504,12 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                     if (hit0 && hit1) {
                         bool swap = t1n < t0n;
                         int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                        if ((uint32_t)sp < ISECT_LDS_STACK) st[sp * 64] = farc;
-                        else ovf[((uint32_t)sp - ISECT_LDS_STACK) * 64u] = farc;
-                        sp++;
+                        push(farc);
                         node = nearc;
                     } else if (hit0) node = c0;
                     else if (hit1) node = c1;
                     else pop = true;
+#endif
                 } else {
                     if (type == PRIM_TRI) { test_tri(n0, n1, n2, start, o, d, h); if (STATS) s_tri++; }
                     else if (type == PRIM_SPHERE) { test_sphere(n0, n1, start, o, d, f.eps, h); if (STATS) s_sph++; }

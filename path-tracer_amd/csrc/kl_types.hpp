@@ -36,6 +36,14 @@ __host__ __device__ inline int make_leaf(uint32_t type, uint32_t start, uint32_t
     return ~(int)((type << 29) | ((count - 1u) << 26) | start);
 }
 constexpr uint32_t MAX_RECORDS = 1u << 26;  // nodes + primitives
+#ifndef KL_BVH4
+#define KL_BVH4 1            // 1: the traversal kernel walks the 4-wide quantised form of the tree (0: binary, full-precision boxes)
+#endif
+// 4-wide node (KL_BVH4), 16 words:
+//   w0..w2 = node box lo (float)   w3 = exponent bytes ex | ey << 8 | ez << 16 (grid step of axis a = 2^(e_a - 127))
+//   w4..w6 = child lo.x / lo.y / lo.z, one byte per child (byte k = child k)   w7..w9 = child hi.x / hi.y / hi.z
+//   w10..w13 = child references (as in the binary node; NODE_DONE = empty slot)   w14, w15 = 0
+//   child box = lo + byte * step, rounded outwards at build time
 #ifndef KL_BVH_MAX_DEPTH
 #define KL_BVH_MAX_DEPTH 32
 #endif

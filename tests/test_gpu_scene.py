@@ -45,7 +45,7 @@ def test_bvh_guarantees(small_scene):
         st = r.bvh_stats()
     assert (st.spheres, st.quads, st.tris) == (len(s), len(q), len(t))
     assert st.max_depth <= 32 and 1 <= st.max_leaf_size <= 8
-    assert st.leaves <= len(s) + len(q) + len(t) and st.nodes == st.leaves - 1
+    assert st.leaves <= len(s) + len(q) + len(t) and 1 <= st.nodes <= st.leaves - 1     # binary: ==, 4-wide: fewer
     assert st.node_bytes == st.nodes * 64
 
 
