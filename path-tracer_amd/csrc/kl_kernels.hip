@@ -288,7 +288,7 @@ __device__ __forceinline__ uint32_t ref_id(const SceneDev &sc, uint32_t ref) {
 constexpr uint32_t ISECT_WAVES = 4;          // waves per workgroup
 constexpr uint32_t ISECT_CHUNK = 256;        // rays a wave takes from the global counter at a time
 #ifndef KL_ISECT_REFILL
-#define KL_ISECT_REFILL 40
+#define KL_ISECT_REFILL 48
 #endif
 #ifndef KL_ISECT_COOP
 #define KL_ISECT_COOP 1            // quad-cooperative LDS-DMA record fetch (0: every lane loads its own record)
