@@ -43,7 +43,7 @@ def load_textures():
 
 def cpu_baseline(scene_arrays, textures, width, height, bounces, budget_s):
     """Times the CPU oracle (oracle/kl_oracle.c, OpenMP) on the host cores over a bounded sample of
-    the same workload: whole rows of frame 0, as many as fit the time budget. Test infrastructure
+    the same workload: whole frames 0, 1, ... for as long as the time budget lasts. Test infrastructure
     used as a reported baseline only; nothing it computes enters the GPU result."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import kloracle as ko
@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--blobs", type=int, default=1000)
     ap.add_argument("--tris-per-blob", type=int, default=1000)
     ap.add_argument("--frames-in-flight", type=int, default=0)
+    ap.add_argument("--lanes", type=int, default=0, help="batches traced concurrently on separate HIP streams (0 = library default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events around the intersect kernel")
     args = ap.parse_args()
@@ -118,7 +119,7 @@ def main():
     r.upload_texture(kl.TEX_ALBEDO, tx)
     bvh = r.bvh_stats()
     r.update_params(max_bounces=args.bounces, max_frames=0, frames_in_flight=args.frames_in_flight,
-                    profile_kernels=0 if args.no_profile else 1)
+                    batch_lanes=args.lanes, profile_kernels=0 if args.no_profile else 1)
     npix = args.width * args.height
     if world > 1:
         from klrender import dist as kdist
@@ -199,7 +200,8 @@ def main():
                     "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(n_node, 2), "tris_per_ray": round(n_tri, 2),
                     "spheres_per_ray": round(n_sph, 3), "quads_per_ray": round(n_quad, 3),
                     "flat_prims_per_ray": int(bvh.flat_spheres + bvh.flat_quads + bvh.flat_tris),
-                    "note": "algorithmic bytes (SURVEY 8d formula) / HIP-event time of k_intersect_bvh; BVH+triangles (83 MB) live in "
+                    "note": "algorithmic bytes (64 B per node visited, 48 B per triangle/quad and 16 B per sphere tested, 112 B of "
+                            "queue traffic per ray) / HIP-event time of k_intersect_bvh; nodes + triangles of this scene fit in "
                             "L2/Infinity Cache, so this figure may exceed the HBM peak: `traffic` is what actually crossed the fabric",
                     "rays_per_launch": round(rays_rank / tm.intersect_launches, 1),
                     "launches": int(tm.intersect_launches), "avg_launch_ms": round(tm.intersect_ms / tm.intersect_launches, 4),

@@ -91,7 +91,9 @@ typedef struct kl_params {
     uint32_t fused_compaction; /* 1: shade pushes survivors itself; 0: separate compact kernel */
     uint32_t collect_stats;    /* 1: traversal kernels count nodes/primitives/active lanes (slower) */
     uint32_t profile_kernels;  /* 1: HIP events around every intersect launch, see kl_get_timing */
-    uint32_t reserved[5];
+    uint32_t batch_lanes;      /* batches traced concurrently on separate HIP streams, each with its own queues: 0 = default (2),
+                                  1 = one stream, at most 4. The image does not depend on it (batches accumulate in frame order). */
+    uint32_t reserved[4];
 } kl_params;
 
 typedef struct kl_counters {

@@ -44,6 +44,20 @@ template <typename T> struct DevBuf {
 };
 }  // namespace
 
+constexpr uint32_t KL_MAX_BATCH_LANES = 4;
+struct BatchLane {
+    hipStream_t stream = nullptr;
+    DevBuf<float4> d_od[2], d_tp[2], d_hits, d_raw;
+    DevBuf<float2> d_d2[2];
+    DevBuf<uint32_t> d_qctl;          // count[0..B], head[0..B]
+    DevBuf<int> d_overflow;           // traversal stack entries beyond the LDS part
+    hipEvent_t done = nullptr;        // recorded after the lane's latest accumulate
+    void release() {
+        for (int k = 0; k < 2; k++) { d_od[k].release(); d_d2[k].release(); d_tp[k].release(); }
+        d_hits.release(); d_raw.release(); d_qctl.release(); d_overflow.release();
+    }
+};
+
 struct kl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -66,11 +80,14 @@ struct kl_ctx {
     // wavefront state
     uint32_t slots = 0;               // frames in flight the buffers are sized for
     uint32_t segcap = 0;              // entries per queue segment
-    DevBuf<float4> d_od[2], d_tp[2], d_hits, d_raw, d_acc, d_last_raw;
-    DevBuf<float2> d_d2[2];
-    DevBuf<uint32_t> d_qctl;          // count[0..B], head[0..B]
+    // Batches are independent until they accumulate, so consecutive batches run on different HIP streams
+    // ("lanes"), each with its own queues: while one batch drains the long tail of a traversal launch, the
+    // next one already fills the CUs that fell idle. Lane 0 is the context's own stream.
+    BatchLane lanes[KL_MAX_BATCH_LANES];
+    uint32_t n_lanes = 0;             // lanes whose buffers are allocated
+    hipEvent_t ev_start = nullptr;    // everything queued on the context stream before a render call
+    DevBuf<float4> d_acc, d_last_raw;
     DevBuf<Counters> d_counters;
-    DevBuf<int> d_overflow;           // traversal stack entries beyond the LDS part
     DevBuf<uchar4> d_resolve;
     // bookkeeping
     uint64_t frames_total = 0, paths_total = 0;
@@ -113,7 +130,13 @@ uint32_t choose_slots(const kl_ctx *c) {
     return std::min(f, KL_MAX_FRAMES_IN_FLIGHT);
 }
 
-kl_status ensure_buffers(kl_ctx *c) {
+uint32_t choose_lanes(const kl_ctx *c) {
+    uint32_t n = c->params.batch_lanes ? c->params.batch_lanes : 2u;
+    return std::min(n, KL_MAX_BATCH_LANES);
+}
+
+// buffers of the first `lanes` batch lanes (and their streams and events)
+kl_status ensure_buffers(kl_ctx *c, uint32_t lanes = 1) {
     KL_HIP(c, hipSetDevice(c->device));
     const uint32_t slots = choose_slots(c);
     const size_t cap = (size_t)slots * c->npl;
@@ -122,11 +145,24 @@ kl_status ensure_buffers(kl_ctx *c) {
     const size_t groups = (cap + 63) / 64;
     c->segcap = (uint32_t)((groups + KL_QUEUE_SEGMENTS - 1) / KL_QUEUE_SEGMENTS * 64);
     const size_t qcap = (size_t)c->segcap * KL_QUEUE_SEGMENTS;
-    for (int k = 0; k < 2; k++) {
-        KL_HIP(c, c->d_od[k].alloc(qcap)); KL_HIP(c, c->d_d2[k].alloc(qcap)); KL_HIP(c, c->d_tp[k].alloc(qcap));
+    lanes = std::max(1u, std::min(lanes, KL_MAX_BATCH_LANES));
+    for (uint32_t l = 0; l < lanes; l++) {
+        BatchLane &L = c->lanes[l];
+        if (!L.stream) {
+            if (l == 0) L.stream = c->stream;
+            else KL_HIP(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        }
+        if (!L.done) KL_HIP(c, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        for (int k = 0; k < 2; k++) {
+            KL_HIP(c, L.d_od[k].alloc(qcap)); KL_HIP(c, L.d_d2[k].alloc(qcap)); KL_HIP(c, L.d_tp[k].alloc(qcap));
+        }
+        KL_HIP(c, L.d_hits.alloc(qcap));
+        KL_HIP(c, L.d_raw.alloc(cap));
+        KL_HIP(c, L.d_qctl.alloc(2 * ((size_t)c->params.max_bounces + 2) * KL_QUEUE_SEGMENTS * CTR_STRIDE));
+        KL_HIP(c, L.d_overflow.alloc(intersect_overflow_ints(c->lc)));
     }
-    KL_HIP(c, c->d_hits.alloc(qcap));
-    KL_HIP(c, c->d_raw.alloc(cap));
+    c->n_lanes = std::max(c->n_lanes, lanes);
+    if (!c->ev_start) KL_HIP(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
     bool fresh = c->d_acc.n != c->npl;
     KL_HIP(c, c->d_acc.alloc(c->npl));
     KL_HIP(c, c->d_last_raw.alloc(c->npl));
@@ -134,12 +170,10 @@ kl_status ensure_buffers(kl_ctx *c) {
         KL_HIP(c, hipMemsetAsync(c->d_acc.p, 0, c->npl * sizeof(float4), c->stream));
         KL_HIP(c, hipMemsetAsync(c->d_last_raw.p, 0, c->npl * sizeof(float4), c->stream));
     }
-    KL_HIP(c, c->d_qctl.alloc(2 * ((size_t)c->params.max_bounces + 2) * KL_QUEUE_SEGMENTS * CTR_STRIDE));
     if (!c->d_counters.p) {
         KL_HIP(c, c->d_counters.alloc(1));
         KL_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream));
     }
-    KL_HIP(c, c->d_overflow.alloc(intersect_overflow_ints(c->lc)));
     return KL_OK;
 }
 
@@ -151,10 +185,9 @@ hipEvent_t get_event(kl_ctx *c) {
 }
 void drain_events(kl_ctx *c) {
     if (c->pending.empty()) return;
-    (void)hipStreamSynchronize(c->stream);
     for (const EventPair &p : c->pending) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             if (p.kind == 0) { c->timing.intersect_ms += ms; c->timing.intersect_launches++; }
             else { c->timing.render_ms += ms; c->timing.render_calls++; }
         }
@@ -195,45 +228,47 @@ bool use_bvh(const kl_ctx *c) {
     return c->n_prims > KL_BRUTE_AUTO_LIMIT;
 }
 
-kl_status timed_intersect(kl_ctx *c, const FrameDev &f, RayQueue q, uint32_t *count, uint32_t *head, uint32_t max_rays) {
+kl_status timed_intersect(kl_ctx *c, BatchLane &L, const FrameDev &f, RayQueue q, uint32_t *count, uint32_t *head, uint32_t max_rays) {
     hipEvent_t a = nullptr, b = nullptr;
     const bool bvh = use_bvh(c);
     if (bvh && scene_has_flat(c->sc))
-        launch_intersect_flat(c->stream, c->lc, c->sc, f, q, c->d_hits.p, count, c->d_counters.p, c->params.collect_stats != 0, max_rays);
+        launch_intersect_flat(L.stream, c->lc, c->sc, f, q, L.d_hits.p, count, c->d_counters.p, c->params.collect_stats != 0, max_rays);
     // the events bracket the dominant kernel only (k_intersect_bvh, or the flat loop for small scenes)
     if (c->params.profile_kernels) {
         if (c->pending.size() >= KL_MAX_PENDING_EVENTS) drain_events(c);
         a = get_event(c); b = get_event(c);
-        if (a && b) KL_HIP(c, hipEventRecord(a, c->stream));
+        if (a && b) KL_HIP(c, hipEventRecord(a, L.stream));
     }
-    launch_intersect(c->stream, c->lc, c->sc, f, q, c->d_hits.p, count, head, c->d_counters.p, c->d_overflow.p, bvh,
+    launch_intersect(L.stream, c->lc, c->sc, f, q, L.d_hits.p, count, head, c->d_counters.p, L.d_overflow.p, bvh,
                      c->params.collect_stats != 0, max_rays);
-    if (a && b) { KL_HIP(c, hipEventRecord(b, c->stream)); c->pending.push_back({a, b, 0}); }
+    if (a && b) { KL_HIP(c, hipEventRecord(b, L.stream)); c->pending.push_back({a, b, 0}); }
     return KL_OK;
 }
 
-// one wavefront batch: frames [first, first+nslots) traced together, then accumulated in order
-kl_status render_batch(kl_ctx *c, uint32_t first, uint32_t nslots, bool camera_change) {
+// one wavefront batch on lane L: frames [first, first+nslots) traced together, then accumulated in order.
+// `after` (may be null): the accumulate of the batch before this one, which this batch's accumulate follows.
+kl_status render_batch(kl_ctx *c, BatchLane &L, hipEvent_t after, uint32_t first, uint32_t nslots, bool camera_change) {
     FrameDev f = make_frame(c, first, nslots);
     const uint32_t B = c->params.max_bounces;
     // count[b] / head[b]: one word per queue segment and bounce
     const size_t S = (size_t)KL_QUEUE_SEGMENTS * CTR_STRIDE;      // words per bounce level
-    uint32_t *count = c->d_qctl.p, *head = c->d_qctl.p + (size_t)(B + 2) * S;
+    uint32_t *count = L.d_qctl.p, *head = L.d_qctl.p + (size_t)(B + 2) * S;
     const uint32_t max_rays = nslots * c->npl;
-    RayQueue q[2] = { {c->d_od[0].p, c->d_d2[0].p, c->d_tp[0].p}, {c->d_od[1].p, c->d_d2[1].p, c->d_tp[1].p} };
+    RayQueue q[2] = { {L.d_od[0].p, L.d_d2[0].p, L.d_tp[0].p}, {L.d_od[1].p, L.d_d2[1].p, L.d_tp[1].p} };
     const bool fused = c->params.fused_compaction != 0;
     const uint32_t levels = c->mode == KL_MODE_PT ? B : (c->mode == KL_MODE_AO ? 2u : 1u);
-    KL_HIP(c, hipMemsetAsync(count, 0, (size_t)(levels + 1) * S * sizeof(uint32_t), c->stream));
-    KL_HIP(c, hipMemsetAsync(head, 0, (size_t)(levels + 1) * S * sizeof(uint32_t), c->stream));
-    launch_generate(c->stream, c->lc, f, q[0], count);
+    KL_HIP(c, hipMemsetAsync(count, 0, (size_t)(levels + 1) * S * sizeof(uint32_t), L.stream));
+    KL_HIP(c, hipMemsetAsync(head, 0, (size_t)(levels + 1) * S * sizeof(uint32_t), L.stream));
+    launch_generate(L.stream, c->lc, f, q[0], count);
     for (uint32_t b = 0; b < levels; b++) {
         RayQueue qi = q[b & 1u], qo = q[(b + 1u) & 1u];
-        kl_status s = timed_intersect(c, f, qi, count + (size_t)b * S, head + (size_t)b * S, max_rays);
+        kl_status s = timed_intersect(c, L, f, qi, count + (size_t)b * S, head + (size_t)b * S, max_rays);
         if (s != KL_OK) return s;
-        launch_shade(c->stream, c->lc, c->sc, f, qi, c->d_hits.p, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, c->d_raw.p, b, fused, max_rays);
-        if (!fused && b + 1 < levels) launch_compact(c->stream, c->lc, f, qi, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, max_rays);
+        launch_shade(L.stream, c->lc, c->sc, f, qi, L.d_hits.p, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, L.d_raw.p, b, fused, max_rays);
+        if (!fused && b + 1 < levels) launch_compact(L.stream, c->lc, f, qi, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, max_rays);
     }
-    launch_accumulate(c->stream, c->lc, f, c->d_raw.p, c->d_acc.p, c->d_last_raw.p, camera_change, c->accum_mode);
+    if (after) KL_HIP(c, hipStreamWaitEvent(L.stream, after, 0));
+    launch_accumulate(L.stream, c->lc, f, L.d_raw.p, c->d_acc.p, c->d_last_raw.p, camera_change, c->accum_mode);
     KL_HIP(c, hipGetLastError());
     return KL_OK;
 }
@@ -268,7 +303,7 @@ kl_status kl_default_params(kl_params *p) {
     std::memset(p, 0, sizeof *p);
     p->max_bounces = 32; p->max_frames = 30; p->eps = 0.001f; p->max_dist = 5000.0f;
     p->ao_length = 1.0f; p->hdri_strength = 1.0f; p->accel = KL_ACCEL_AUTO;
-    p->frames_in_flight = 0; p->fused_compaction = 1; p->collect_stats = 0; p->profile_kernels = 0;
+    p->frames_in_flight = 0; p->fused_compaction = 1; p->collect_stats = 0; p->profile_kernels = 0; p->batch_lanes = 0;
     return KL_OK;
 }
 kl_status kl_default_camera(kl_camera *cam) {
@@ -319,9 +354,16 @@ kl_status kl_destroy(kl_ctx *c) {
     for (const EventPair &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
     c->d_rec.release(); c->d_tri_uv.release(); c->d_mats.release(); c->d_flatq.release();
-    for (int k = 0; k < 2; k++) { c->d_tex[k].release(); c->d_od[k].release(); c->d_d2[k].release(); c->d_tp[k].release(); }
-    c->d_hits.release(); c->d_raw.release(); c->d_acc.release(); c->d_last_raw.release();
-    c->d_qctl.release(); c->d_counters.release(); c->d_resolve.release(); c->d_overflow.release();
+    for (int k = 0; k < 2; k++) c->d_tex[k].release();
+    for (uint32_t l = 0; l < KL_MAX_BATCH_LANES; l++) {
+        BatchLane &L = c->lanes[l];
+        if (l > 0 && L.stream) { (void)hipStreamSynchronize(L.stream); (void)hipStreamDestroy(L.stream); }
+        if (L.done) (void)hipEventDestroy(L.done);
+        L.release();
+    }
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    c->d_acc.release(); c->d_last_raw.release();
+    c->d_counters.release(); c->d_resolve.release();
     (void)hipStreamDestroy(c->stream);
     delete c;
     return KL_OK;
@@ -361,6 +403,7 @@ kl_status kl_set_params(kl_ctx *c, const kl_params *p) {
     if (p->max_bounces == 0 || p->max_bounces > KL_MAX_BOUNCES) return fail(c, KL_E_LIMIT, "max_bounces must be 1..4096");
     if (p->frames_in_flight > KL_MAX_FRAMES_IN_FLIGHT) return fail(c, KL_E_LIMIT, "frames_in_flight must be <= 64");
     if (p->accel > KL_ACCEL_BVH) return fail(c, KL_E_INVALID, "bad accel");
+    if (p->batch_lanes > KL_MAX_BATCH_LANES) return fail(c, KL_E_LIMIT, "batch_lanes must be <= 4");
     if (!(p->max_dist > 0.0f) || !(p->eps >= 0.0f)) return fail(c, KL_E_INVALID, "bad eps/max_dist");
     KL_HIP(c, hipStreamSynchronize(c->stream));
     c->params = *p;
@@ -422,7 +465,7 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
 #if KL_BVH4
     for (uint32_t k = 0; k < n_nodes; k++) {
         uint32_t w[16]; std::memcpy(w, &bvh.nodes4[(size_t)k * 16], sizeof w);
-        for (int j = 10; j < 14; j++) w[j] = (uint32_t)patch_child((int32_t)w[j]);
+        for (int j = 12; j < 16; j++) w[j] = (uint32_t)patch_child((int32_t)w[j]);
         std::memcpy(&rec[4 * (size_t)k], w, sizeof w);
     }
     const int32_t tree_root = bvh.root4;
@@ -545,7 +588,10 @@ kl_status kl_render_frames(kl_ctx *c, uint32_t n, uint32_t first_frame) {
     if (!c) return KL_E_INVALID;
     if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");
     if (c->npl == 0 || n == 0) return KL_OK;
-    kl_status s = ensure_buffers(c);
+    // as many lanes as there are batches to overlap
+    const uint32_t batches = (n + choose_slots(c) - 1) / choose_slots(c);
+    const uint32_t lanes = std::min(choose_lanes(c), batches);
+    kl_status s = ensure_buffers(c, lanes);
     if (s != KL_OK) return s;
     uint32_t frame = first_frame == KL_CONTINUE ? c->frame : first_frame;
     if ((uint64_t)frame + n > 0xFFFFFFFEull) return fail(c, KL_E_LIMIT, "frame index overflow");
@@ -553,25 +599,42 @@ kl_status kl_render_frames(kl_ctx *c, uint32_t n, uint32_t first_frame) {
     if (c->pending.size() >= KL_MAX_PENDING_EVENTS) drain_events(c);
     ea = get_event(c); eb = get_event(c);
     if (ea && eb) KL_HIP(c, hipEventRecord(ea, c->stream));
-    uint32_t left = n;
+    if (lanes > 1) {
+        // the other lanes start after everything already queued on the context stream
+        KL_HIP(c, hipEventRecord(c->ev_start, c->stream));
+        for (uint32_t l = 1; l < lanes; l++) KL_HIP(c, hipStreamWaitEvent(c->lanes[l].stream, c->ev_start, 0));
+    }
+    uint32_t left = n, batch = 0;
+    hipEvent_t last_done = nullptr;            // accumulate of the previous batch (null: it ran on this lane or there is none)
+    uint32_t last_lane = 0;
+    bool lane_used[KL_MAX_BATCH_LANES] = { false, false, false, false };
     while (left) {
         const uint32_t mf = c->params.max_frames;
+        const uint32_t l = batch % lanes;
+        BatchLane &L = c->lanes[l];
+        hipEvent_t after = (batch > 0 && last_lane != l) ? last_done : nullptr;
         uint32_t k;
         if (mf && frame >= mf) {
             // past SAMPLES the raw frame is the accumulation texel (RawFrame.glsl:461-463): nothing to trace
             k = std::min(left, 1024u);
             FrameDev f = make_frame(c, frame, k);
-            launch_accumulate(c->stream, c->lc, f, c->d_raw.p, c->d_acc.p, c->d_last_raw.p, false, c->accum_mode);
+            if (after) KL_HIP(c, hipStreamWaitEvent(L.stream, after, 0));
+            launch_accumulate(L.stream, c->lc, f, L.d_raw.p, c->d_acc.p, c->d_last_raw.p, false, c->accum_mode);
         } else {
             k = std::min(left, c->slots);
             if (mf) k = std::min(k, mf - frame);
-            if ((s = render_batch(c, frame, k, c->camera_change)) != KL_OK) return s;
+            if ((s = render_batch(c, L, after, frame, k, c->camera_change)) != KL_OK) return s;
             c->paths_total += (uint64_t)k * c->npl;
         }
+        if (lanes > 1) { KL_HIP(c, hipEventRecord(L.done, L.stream)); last_done = L.done; }
+        last_lane = l; lane_used[l] = true;
         c->camera_change = false;       // GLSL_Renderer.cpp:348
-        frame += k; left -= k;
+        frame += k; left -= k; batch++;
         c->frames_total += k;
     }
+    // the context stream resumes after every lane: later calls (reads, resolves, the next render) stay ordered
+    for (uint32_t l = 1; l < lanes; l++)
+        if (lane_used[l]) KL_HIP(c, hipStreamWaitEvent(c->stream, c->lanes[l].done, 0));
     c->frame = frame;                   // iFrame++ per frame, GLSL_Renderer.cpp:347
     if (ea && eb) { KL_HIP(c, hipEventRecord(eb, c->stream)); c->pending.push_back({ea, eb, 1}); }
     return KL_OK;
@@ -651,7 +714,7 @@ kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, f
     KL_HIP(c, b_od.alloc(n)); KL_HIP(c, b_hits.alloc(n)); KL_HIP(c, b_d2.alloc(n)); KL_HIP(c, b_uv.alloc(n));
     KL_HIP(c, b_t.alloc(n)); KL_HIP(c, b_prim.alloc(n)); KL_HIP(c, b_ctl.alloc(2));   // one segment: count, head
     if (!c->d_counters.p) { KL_HIP(c, c->d_counters.alloc(1)); KL_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream)); }
-    KL_HIP(c, c->d_overflow.alloc(intersect_overflow_ints(c->lc)));
+    KL_HIP(c, c->lanes[0].d_overflow.alloc(intersect_overflow_ints(c->lc)));
     const uint32_t ctl[2] = { n, 0 };
     KL_HIP(c, hipMemcpyAsync(b_od.p, od.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     KL_HIP(c, hipMemcpyAsync(b_d2.p, d2.data(), n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
@@ -661,7 +724,7 @@ kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, f
     RayQueue q = { b_od.p, b_d2.p, nullptr };
     if (use_bvh(c) && scene_has_flat(c->sc))
         launch_intersect_flat(c->stream, c->lc, c->sc, f, q, b_hits.p, &b_ctl.p[0], c->d_counters.p, c->params.collect_stats != 0, n);
-    launch_intersect(c->stream, c->lc, c->sc, f, q, b_hits.p, &b_ctl.p[0], &b_ctl.p[1], c->d_counters.p, c->d_overflow.p, use_bvh(c),
+    launch_intersect(c->stream, c->lc, c->sc, f, q, b_hits.p, &b_ctl.p[0], &b_ctl.p[1], c->d_counters.p, c->lanes[0].d_overflow.p, use_bvh(c),
                      c->params.collect_stats != 0, n);
     launch_unpack_hits(c->stream, c->sc, b_hits.p, n, b_t.p, b_prim.p, b_uv.p);
     KL_HIP(c, hipMemcpyAsync(t, b_t.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));

@@ -166,7 +166,10 @@ void pad_box(Box &b) {
 namespace {
 struct Child4 { Box box; int32_t ref; };
 
-uint32_t collapse_node(const HostBVH &bvh, int32_t node2, std::vector<uint32_t> &out, uint32_t depth, uint32_t &max_depth) {
+// Fills 4-wide node `idx` (already allocated in `out`) from binary node `node2`. The inner children of a node
+// get consecutive indices ("siblings side by side"): a ray that enters one child usually comes back for its
+// neighbours a few steps later, and two 64-byte siblings share a 128-byte cache line.
+void collapse_node(const HostBVH &bvh, int32_t node2, uint32_t idx, std::vector<uint32_t> &out, uint32_t depth, uint32_t &max_depth) {
     auto child_of = [&](int32_t n2, int k) {
         const float *o = &bvh.nodes[(size_t)n2 * 16];
         Child4 c;
@@ -185,22 +188,20 @@ uint32_t collapse_node(const HostBVH &bvh, int32_t node2, std::vector<uint32_t> 
         ch.push_back(child_of(open, 1));
     }
     max_depth = std::max(max_depth, depth);
-    const uint32_t idx = (uint32_t)(out.size() / 16);
-    out.resize(out.size() + 16, 0u);
     Box nb; nb.reset();
     for (const Child4 &c : ch) nb.grow(c.box);
     uint32_t w[16]; std::memset(w, 0, sizeof w);
-    uint32_t ebyte[3]; double scale[3];
+    double scale[3];
     for (int a = 0; a < 3; a++) {
         std::memcpy(&w[a], &nb.lo[a], 4);
         double ext = (double)nb.hi[a] - (double)nb.lo[a];
         int e = ext > 0.0 ? (int)std::ceil(std::log2(ext / 255.0)) : -100;
         if (e < -100) e = -100;
         while (std::ldexp(255.0, e) < ext) e++;          // guard the rounding of log2
-        ebyte[a] = (uint32_t)(e + 127);
         scale[a] = std::ldexp(1.0, e);
+        const float step = (float)scale[a];              // a power of two: exact
+        std::memcpy(&w[3 + a], &step, 4);
     }
-    w[3] = ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16);
     for (int k = 0; k < 4; k++) {
         uint32_t qlo[3] = {255, 255, 255}, qhi[3] = {0, 0, 0};     // empty slot: inverted box, never entered
         if (k < (int)ch.size()) {
@@ -211,15 +212,22 @@ uint32_t collapse_node(const HostBVH &bvh, int32_t node2, std::vector<uint32_t> 
                 qhi[a] = (uint32_t)std::min(255.0, std::max(0.0, h));
             }
         }
-        for (int a = 0; a < 3; a++) { w[4 + a] |= qlo[a] << (8 * k); w[7 + a] |= qhi[a] << (8 * k); }
+        for (int a = 0; a < 3; a++) { w[6 + a] |= qlo[a] << (8 * k); w[9 + a] |= qhi[a] << (8 * k); }
     }
+    uint32_t next = (uint32_t)(out.size() / 16);           // inner children: consecutive indices from here
+    uint32_t n_inner = 0;
+    for (const Child4 &c : ch) n_inner += c.ref >= 0 ? 1u : 0u;
+    out.resize(out.size() + (size_t)16 * n_inner, 0u);
     for (int k = 0; k < 4; k++) {
         int32_t ref = NODE_DONE;
-        if (k < (int)ch.size()) ref = ch[k].ref >= 0 ? (int32_t)collapse_node(bvh, ch[k].ref, out, depth + 1, max_depth) : ch[k].ref;
-        std::memcpy(&w[10 + k], &ref, 4);
+        if (k < (int)ch.size()) ref = ch[k].ref >= 0 ? (int32_t)next++ : ch[k].ref;
+        std::memcpy(&w[12 + k], &ref, 4);
     }
+    // an empty slot repeats child 0: always a valid reference (see kl_types.hpp)
+    for (int k = (int)ch.size(); k < 4; k++) w[12 + k] = w[12];
     std::memcpy(&out[(size_t)idx * 16], w, sizeof w);
-    return idx;
+    for (int k = 0; k < (int)ch.size(); k++)
+        if (ch[k].ref >= 0) collapse_node(bvh, ch[k].ref, w[12 + k], out, depth + 1, max_depth);
 }
 }  // namespace
 
@@ -228,7 +236,9 @@ void collapse_bvh4(HostBVH &bvh) {
     bvh.root4 = bvh.root;                       // an empty tree or a lone leaf stays what it is
     if (bvh.root >= 0 && bvh.root != NODE_DONE) {
         bvh.nodes4.reserve(bvh.nodes.size() / 2);
-        bvh.root4 = (int32_t)collapse_node(bvh, bvh.root, bvh.nodes4, 1, bvh.depth4);
+        bvh.nodes4.assign(16, 0u);                // the root is node 0
+        collapse_node(bvh, bvh.root, 0u, bvh.nodes4, 1, bvh.depth4);
+        bvh.root4 = 0;
     }
 }
 

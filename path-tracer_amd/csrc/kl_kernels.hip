@@ -286,7 +286,10 @@ __device__ __forceinline__ uint32_t ref_id(const SceneDev &sc, uint32_t ref) {
 
 // ------------------------------------------------------------------ intersect: BVH
 constexpr uint32_t ISECT_WAVES = 4;          // waves per workgroup
-constexpr uint32_t ISECT_CHUNK = 256;        // rays a wave takes from the global counter at a time
+#ifndef KL_ISECT_CHUNK
+#define KL_ISECT_CHUNK 64          // small chunks: a wave that ends up with the last rays of a segment holds few of them
+#endif
+constexpr uint32_t ISECT_CHUNK = KL_ISECT_CHUNK;   // rays a wave takes from its segment's counter at a time
 #ifndef KL_ISECT_REFILL
 #define KL_ISECT_REFILL 48
 #endif
@@ -318,6 +321,7 @@ constexpr uint32_t ISECT_OVF_STACK = ISECT_STACK_MAX > ISECT_LDS_STACK ? ISECT_S
 constexpr uint32_t STAGE_REGION_F4 = 65;      // 64 float4 (1 KiB) of payload + 16 bytes of skew per region
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) int lds_int_t;      // explicit LDS pointers: stack accesses stay ds_read / ds_write
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
 template <int K>
@@ -338,8 +342,8 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
     __shared__ float4 stage[ISECT_WAVES][4][STAGE_REGION_F4];
 #endif
     const uint32_t lane = lane_id();
-    const uint32_t wave_in_block = threadIdx.x >> 6;
-    int *st = &stack[wave_in_block][0][lane];
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: LDS bases stay scalar
+    lds_int_t *st = (lds_int_t *)&stack[wave_in_block][0][lane];
     int *ovf = overflow + ((size_t)(blockIdx.x * ISECT_WAVES + wave_in_block) * ISECT_OVF_STACK) * 64u + lane;
     // this workgroup serves queue segment blockIdx % nseg; its waves pull ray chunks from that segment's head
     const uint32_t seg = blockIdx.x % f.nseg;
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                 node = sc.root;
                 active = true;
                 if (node == NODE_DONE || !ray_finite(o, d)) {    // empty tree, or a NaN ray (hits nothing)
-                    if (!seeded) hits[ray] = make_float4(h.t, __uint_as_float(REF_MISS), 0.0f, 0.0f);
+                    if (!seeded) hits[ray] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);      // a miss
                     active = false;
                 }
             }
@@ -418,12 +422,13 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
             coop_fetch_one<1>(sc.rec, my_offset, slice, regions + STAGE_REGION_F4);
             coop_fetch_one<2>(sc.rec, my_offset, slice, regions + 2 * STAGE_REGION_F4);
             coop_fetch_one<3>(sc.rec, my_offset, slice, regions + 3 * STAGE_REGION_F4);
-            // the entry a pop would return is read now, under the shadow of the record fetch: a step either
-            // pushes or pops, so it is still the top of the stack when the pop happens
-            int top = NODE_DONE;
-            if (active && sp > 0)
-                top = (uint32_t)(sp - 1) < ISECT_LDS_STACK ? st[(sp - 1) * 64] : ovf[((uint32_t)(sp - 1) - ISECT_LDS_STACK) * 64u];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the four LDS-DMA loads have landed
+            // the entry a pop would return is read together with the record, long before the pop needs it: a
+            // step either pushes or pops, so it is still the top of the stack then. The LDS read is
+            // unconditional (index clamped into the LDS part); entries beyond it are rare.
+            const uint32_t tp = sp > 0 ? (uint32_t)(sp - 1) : 0u;
+            int top = st[min(tp, ISECT_LDS_STACK - 1u) * 64u];
+            if (active && tp >= ISECT_LDS_STACK) top = ovf[(tp - ISECT_LDS_STACK) * 64u];
             const float4 *mine = &stage[wave_in_block][lane & 3u][(lane >> 2) * 4u];
             const float4 n0 = mine[0], n1 = mine[1], n2 = mine[2], n3 = mine[3];
 #endif
@@ -450,19 +455,17 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                     if (STATS) s_nodes++;
 #if KL_BVH4
                     // four child boxes on the node's 8-bit grid: plane = lo + byte * step, so along the ray
-                    // t = byte * (step * 1/d) + (lo - o) * 1/d; near and far planes are picked by the sign of 1/d
-                    const uint32_t ew = __float_as_uint(n0.w);
-                    const float Ax = __uint_as_float((ew & 0xFFu) << 23) * id.x;
-                    const float Ay = __uint_as_float(((ew >> 8) & 0xFFu) << 23) * id.y;
-                    const float Az = __uint_as_float(((ew >> 16) & 0xFFu) << 23) * id.z;
+                    // t = byte * (step * 1/d) + (lo - o) * 1/d; near and far planes are picked by the sign of 1/d.
+                    // An empty slot holds an inverted box and fails the test by itself.
+                    const float Ax = n0.w * id.x, Ay = n1.x * id.y, Az = n1.y * id.z;
                     const float Bx = fmaf(n0.x, id.x, nood.x), By = fmaf(n0.y, id.y, nood.y), Bz = fmaf(n0.z, id.z, nood.z);
-                    const uint32_t lox = __float_as_uint(n1.x), loy = __float_as_uint(n1.y), loz = __float_as_uint(n1.z);
-                    const uint32_t hix = __float_as_uint(n1.w), hiy = __float_as_uint(n2.x), hiz = __float_as_uint(n2.y);
+                    const uint32_t lox = __float_as_uint(n1.z), loy = __float_as_uint(n1.w), loz = __float_as_uint(n2.x);
+                    const uint32_t hix = __float_as_uint(n2.y), hiy = __float_as_uint(n2.z), hiz = __float_as_uint(n2.w);
                     const bool px = id.x >= 0.0f, py = id.y >= 0.0f, pz = id.z >= 0.0f;
                     const uint32_t nx = px ? lox : hix, fx = px ? hix : lox;
                     const uint32_t ny = py ? loy : hiy, fy = py ? hiy : loy;
                     const uint32_t nz = pz ? loz : hiz, fz = pz ? hiz : loz;
-                    int ref[4] = { __float_as_int(n2.z), __float_as_int(n2.w), __float_as_int(n3.x), __float_as_int(n3.y) };
+                    int ref[4] = { __float_as_int(n3.x), __float_as_int(n3.y), __float_as_int(n3.z), __float_as_int(n3.w) };
                     float key[4];
                     const float inf = __builtin_huge_valf();
 #pragma unroll
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                         const float tnz = fmaf((float)((nz >> (8 * k)) & 0xFFu), Az, Bz), tfz = fmaf((float)((fz >> (8 * k)) & 0xFFu), Az, Bz);
                         const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
                         const float tf = fminf(fminf(tfx, tfy), fminf(tfz, h.t));
-                        key[k] = (tn <= tf && ref[k] != NODE_DONE) ? tn : inf;
+                        key[k] = tn <= tf ? tn : inf;
                     }
                     // sort the four (entry distance, child) pairs, nearest first
                     auto cswap = [&](int a, int b) {
@@ -483,9 +486,17 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                     };
                     cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
                     if (key[0] < inf) {
-                        if (key[3] < inf) push(ref[3]);      // farthest first, so the nearest pending child pops first
-                        if (key[2] < inf) push(ref[2]);
-                        if (key[1] < inf) push(ref[1]);
+                        // farthest first, so that the nearest pending child pops first
+                        if ((uint32_t)sp + 3u <= ISECT_LDS_STACK) {         // the usual case: all three fit the LDS part
+                            lds_int_t *p = st + sp * 64;
+                            if (key[3] < inf) { *p = ref[3]; p += 64; sp++; }
+                            if (key[2] < inf) { *p = ref[2]; p += 64; sp++; }
+                            if (key[1] < inf) { *p = ref[1]; sp++; }
+                        } else {
+                            if (key[3] < inf) push(ref[3]);
+                            if (key[2] < inf) push(ref[2]);
+                            if (key[1] < inf) push(ref[1]);
+                        }
                         node = ref[0];
                     } else pop = true;
 #else
@@ -525,7 +536,13 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
 #else
                         node = (uint32_t)sp < ISECT_LDS_STACK ? st[sp * 64] : ovf[((uint32_t)sp - ISECT_LDS_STACK) * 64u];
 #endif
-                    } else { hits[ray] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v); active = false; }
+                    } else {
+                        // the address is formed here, from the ray index, rather than carried through the loop in two registers
+                        uint32_t slot = ray;
+                        asm volatile("" : "+v"(slot));
+                        hits[slot] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
+                        active = false;
+                    }
                 }
             }
             am = __ballot(active);

@@ -40,10 +40,12 @@ constexpr uint32_t MAX_RECORDS = 1u << 26;  // nodes + primitives
 #define KL_BVH4 1            // 1: the traversal kernel walks the 4-wide quantised form of the tree (0: binary, full-precision boxes)
 #endif
 // 4-wide node (KL_BVH4), 16 words:
-//   w0..w2 = node box lo (float)   w3 = exponent bytes ex | ey << 8 | ez << 16 (grid step of axis a = 2^(e_a - 127))
-//   w4..w6 = child lo.x / lo.y / lo.z, one byte per child (byte k = child k)   w7..w9 = child hi.x / hi.y / hi.z
-//   w10..w13 = child references (as in the binary node; NODE_DONE = empty slot)   w14, w15 = 0
-//   child box = lo + byte * step, rounded outwards at build time
+//   w0..w2 = node box lo (float)   w3..w5 = grid step of each axis (float, a power of two)
+//   w6..w8 = child lo.x / lo.y / lo.z, one byte per child (byte k = child k)   w9..w11 = child hi.x / hi.y / hi.z
+//   w12..w15 = child references (as in the binary node)
+//   child box = lo + byte * step, rounded outwards at build time. An empty slot holds an inverted box
+//   (lo bytes 255, hi bytes 0), which no ray enters, and repeats the reference of child 0 so that it is a
+//   valid reference whatever rounding does to the box test.
 #ifndef KL_BVH_MAX_DEPTH
 #define KL_BVH_MAX_DEPTH 32
 #endif

@@ -41,7 +41,8 @@ class Params(C.Structure):
     _fields_ = [("max_bounces", C.c_uint32), ("max_frames", C.c_uint32), ("eps", C.c_float),
                 ("max_dist", C.c_float), ("ao_length", C.c_float), ("hdri_strength", C.c_float),
                 ("accel", C.c_uint32), ("frames_in_flight", C.c_uint32), ("fused_compaction", C.c_uint32),
-                ("collect_stats", C.c_uint32), ("profile_kernels", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("collect_stats", C.c_uint32), ("profile_kernels", C.c_uint32), ("batch_lanes", C.c_uint32),
+                ("reserved", C.c_uint32 * 4)]
 
 
 class Counters(C.Structure):
