@@ -25,6 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+VALU_PEAK_TFLOPS = 157.3       # MI355X vector fp32 peak (packed multiply-add on every lane of 256 CUs at 2.4 GHz)
 QUEUE_BYTES_PER_RAY = 112      # write+read of the 40-byte ray plus write+read of the 16-byte hit
 
 
@@ -150,6 +151,7 @@ def main():
     n_sph = cs.sphere_tests / rays_stat - bvh.flat_spheres
     n_quad = cs.quad_tests / rays_stat - bvh.flat_quads
     b_ray = 64.0 * n_node + 48.0 * n_tri + 16.0 * n_sph + 48.0 * n_quad + QUEUE_BYTES_PER_RAY
+    f_ray = 100.0 * n_node + 45.0 * n_tri + 25.0 * n_sph + 90.0 * n_quad
     lane_active = cs.lane_steps_active / max(cs.lane_steps_total, 1)
 
     for _ in range(args.warmup):
@@ -206,7 +208,15 @@ def main():
                     "rays_per_launch": round(rays_rank / tm.intersect_launches, 1),
                     "launches": int(tm.intersect_launches), "avg_launch_ms": round(tm.intersect_ms / tm.intersect_launches, 4),
                     "intersect_share_of_step": round(isect_s / elapsed, 3), "lane_active_frac": round(lane_active, 3),
-                    "grays_per_s_in_kernel": round(rays_rank / isect_s / 1e9, 3)}
+                    "grays_per_s_in_kernel": round(rays_rank / isect_s / 1e9, 3),
+                    "batch_lanes_param": int(r.get_params().batch_lanes),
+                    "timing_note": "with more than one batch lane the traversal launches of neighbouring batches overlap on the GPU, so an "
+                                   "event-bracketed launch lasts longer than the same launch alone (run --lanes 1 for isolated launches)",
+                    # the other ceiling of this kernel: vector fp32. 100 flop per 4-wide node (two 2-child slab tests),
+                    # 45 per triangle, 25 per sphere, 90 per quad
+                    "valu": {"flop_per_ray": round(f_ray, 1), "achieved": round(rays_rank * f_ray / isect_s / 1e12, 2),
+                             "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(rays_rank * f_ray / isect_s / 1e12 / VALU_PEAK_TFLOPS, 4)}}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:

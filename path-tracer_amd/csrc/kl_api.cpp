@@ -79,6 +79,8 @@ struct kl_ctx {
     DevBuf<uchar4> d_tex[2];
     // wavefront state
     uint32_t slots = 0;               // frames in flight the buffers are sized for
+    uint32_t slots_npl = 0;           // ... at this many pixels
+    uint32_t auto_slots = 0, auto_slots_npl = 0;   // automatic batch size, decided once per image size
     uint32_t segcap = 0;              // entries per queue segment
     // Batches are independent until they accumulate, so consecutive batches run on different HIP streams
     // ("lanes"), each with its own queues: while one batch drains the long tail of a traversal launch, the
@@ -120,28 +122,47 @@ void compute_local(kl_ctx *c) {
     c->npl = rows * c->width;
 }
 
-uint32_t choose_slots(const kl_ctx *c) {
+uint32_t choose_slots(kl_ctx *c) {
     uint32_t f = c->params.frames_in_flight;
+    if (f == 0 && c->auto_slots && c->auto_slots_npl == c->npl) return c->auto_slots;    // decided once per image size
     if (f == 0) {
-        // about eight million paths per batch keeps every CU busy through the late bounces
-        uint64_t npl = std::max<uint32_t>(c->npl, 1);
-        f = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, (8u << 20) / npl));
+        // Large batches: every launch ends in a tail of long rays during which the CUs drain, and the tail costs
+        // the same whatever the launch holds, so a batch takes as many frames as memory comfortably allows
+        // (about 112 bytes of queue, hit and raw-frame storage per path; at most a quarter of the free memory
+        // for all lanes together, and at most 128 Mi paths).
+        const uint64_t npl = std::max<uint32_t>(c->npl, 1);
+        uint64_t paths = 128ull << 20;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
+            uint64_t held = 0;                               // what the lanes already hold counts as available
+            for (uint32_t l = 0; l < KL_MAX_BATCH_LANES; l++) held += (uint64_t)c->lanes[l].d_raw.n * 112u;
+            paths = std::min<uint64_t>(paths, ((uint64_t)free_b + held) / 4u / (112u * 2u));
+        }
+        f = (uint32_t)std::min<uint64_t>(KL_MAX_FRAMES_IN_FLIGHT, std::max<uint64_t>(1, paths / npl));
+        while (f > 1 && (uint64_t)f * npl >= (1ull << 31)) f--;
+        c->auto_slots = f; c->auto_slots_npl = c->npl;
     }
-    return std::min(f, KL_MAX_FRAMES_IN_FLIGHT);
+    return std::max(1u, std::min(f, KL_MAX_FRAMES_IN_FLIGHT));
 }
 
-uint32_t choose_lanes(const kl_ctx *c) {
-    uint32_t n = c->params.batch_lanes ? c->params.batch_lanes : 2u;
+uint32_t choose_lanes(kl_ctx *c) {
+    uint32_t n = c->params.batch_lanes;
+    // automatic: a second lane pays while batches are small enough for their tails to matter (measured: +6 % at
+    // 8 Mi paths per batch, nothing at 32 Mi, a small loss beyond)
+    if (n == 0) n = (uint64_t)choose_slots(c) * c->npl < (32ull << 20) ? 2u : 1u;
     return std::min(n, KL_MAX_BATCH_LANES);
 }
 
-// buffers of the first `lanes` batch lanes (and their streams and events)
-kl_status ensure_buffers(kl_ctx *c, uint32_t lanes = 1) {
+// buffers of the first `lanes` batch lanes (and their streams and events), for batches of up to `frames` frames.
+// Capacity only grows while the image size stays: a one-frame call does not shrink what a 64-frame call set up,
+// and does not allocate for 64 frames either.
+kl_status ensure_buffers(kl_ctx *c, uint32_t lanes = 1, uint32_t frames = 1) {
     KL_HIP(c, hipSetDevice(c->device));
-    const uint32_t slots = choose_slots(c);
+    uint32_t slots = std::max(1u, std::min(choose_slots(c), frames));
+    if (c->slots_npl == c->npl && c->slots > slots && c->slots <= choose_slots(c)) slots = c->slots;
     const size_t cap = (size_t)slots * c->npl;
     if (cap >= (1ull << 31)) return fail(c, KL_E_LIMIT, "frames_in_flight x pixels exceeds 2^31 paths");
-    c->slots = slots;
+    c->slots = slots; c->slots_npl = c->npl;
     const size_t groups = (cap + 63) / 64;
     c->segcap = (uint32_t)((groups + KL_QUEUE_SEGMENTS - 1) / KL_QUEUE_SEGMENTS * 64);
     const size_t qcap = (size_t)c->segcap * KL_QUEUE_SEGMENTS;
@@ -589,9 +610,10 @@ kl_status kl_render_frames(kl_ctx *c, uint32_t n, uint32_t first_frame) {
     if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");
     if (c->npl == 0 || n == 0) return KL_OK;
     // as many lanes as there are batches to overlap
-    const uint32_t batches = (n + choose_slots(c) - 1) / choose_slots(c);
+    const uint32_t per_batch = std::max(1u, std::min(choose_slots(c), n));
+    const uint32_t batches = (n + per_batch - 1) / per_batch;
     const uint32_t lanes = std::min(choose_lanes(c), batches);
-    kl_status s = ensure_buffers(c, lanes);
+    kl_status s = ensure_buffers(c, lanes, per_batch);
     if (s != KL_OK) return s;
     uint32_t frame = first_frame == KL_CONTINUE ? c->frame : first_frame;
     if ((uint64_t)frame + n > 0xFFFFFFFEull) return fail(c, KL_E_LIMIT, "frame index overflow");
