@@ -141,13 +141,21 @@ __device__ __forceinline__ void test_tri(float4 a, float4 b, float4 c, uint32_t 
     if (tri_intersect(o, d, V(a.x, a.y, a.z), V(a.w, b.x, b.y), V(b.z, b.w, c.x), t, u, v))
         accept(h, t, make_ref(PRIM_TRI, i), __float_as_uint(c.y), u, v);
 }
+// A 16-byte load from an address that is the same in every lane, through the constant address space: the
+// compiler then uses the scalar cache and scalar registers instead of 64 identical vector loads. Only for data
+// that no kernel writes (scene records and tables, uploaded before any launch).
+typedef float vf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 uload(const float4 *p) {
+    const vf4 v = *(const __attribute__((address_space(4))) vf4 *)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 // all primitives of one type in record range [first, first + n): uniform loads (flat loop, flat pass)
 __device__ __forceinline__ void test_range(const SceneDev &sc, uint32_t type, uint32_t first, uint32_t n, v3 o, v3 d, float eps, Hit &h) {
     for (uint32_t r = first; r < first + n; r++) {
         const float4 *p = sc.rec + 4u * r;
-        if (type == PRIM_SPHERE) test_sphere(p[0], p[1], r, o, d, eps, h);
-        else if (type == PRIM_QUAD) test_quad(p[0], p[1], p[2], p[3], r, o, d, h);
-        else test_tri(p[0], p[1], p[2], r, o, d, h);
+        if (type == PRIM_SPHERE) test_sphere(uload(p), uload(p + 1), r, o, d, eps, h);
+        else if (type == PRIM_QUAD) test_quad(uload(p), uload(p + 1), uload(p + 2), uload(p + 3), r, o, d, h);
+        else test_tri(uload(p), uload(p + 1), uload(p + 2), r, o, d, h);
     }
 }
 __device__ __forceinline__ bool ray_finite(v3 o, v3 d) {
@@ -220,8 +228,8 @@ __global__ __launch_bounds__(256) void k_intersect_brute(SceneDev sc, FrameDev f
 __device__ __forceinline__ void flat_quads(const SceneDev &sc, v3 o, v3 d, Hit &h) {
     const uint32_t nq = sc.flat_count[PRIM_QUAD];
     for (uint32_t k = 0; k < nq; k++) {
-        const float4 F0 = sc.flatq[5 * k], F1 = sc.flatq[5 * k + 1], F2 = sc.flatq[5 * k + 2], F3 = sc.flatq[5 * k + 3];
-        const uint32_t id = __float_as_uint(sc.flatq[5 * k + 4].x);
+        const float4 F0 = uload(sc.flatq + 5 * k), F1 = uload(sc.flatq + 5 * k + 1), F2 = uload(sc.flatq + 5 * k + 2), F3 = uload(sc.flatq + 5 * k + 3);
+        const uint32_t id = __float_as_uint(uload(sc.flatq + 5 * k + 4).x);
         const v3 p = o - V(F0.x, F0.y, F0.z), nor = V(F1.x, F1.y, F1.z);
         const float t = -dot(p, nor) / dot(d, nor);                  // RF:225
         if (t < 0.0f) continue;                                      // RF:226
@@ -321,6 +329,10 @@ constexpr uint32_t ISECT_OVF_STACK = ISECT_STACK_MAX > ISECT_LDS_STACK ? ISECT_S
 constexpr uint32_t STAGE_REGION_F4 = 65;      // 64 float4 (1 KiB) of payload + 16 bytes of skew per region
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef float vf2 __attribute__((ext_vector_type(2)));       // pairs for the packed fp32 multiply-add
+#ifndef KL_ISECT_PK
+#define KL_ISECT_PK 0
+#endif
 typedef __attribute__((address_space(3))) int lds_int_t;      // explicit LDS pointers: stack accesses stay ds_read / ds_write
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
@@ -468,6 +480,22 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                     int ref[4] = { __float_as_int(n3.x), __float_as_int(n3.y), __float_as_int(n3.z), __float_as_int(n3.w) };
                     float key[4];
                     const float inf = __builtin_huge_valf();
+#if KL_ISECT_PK
+                    // (near, far) of one axis in one packed multiply-add
+                    const vf2 Ax2 = { Ax, Ax }, Ay2 = { Ay, Ay }, Az2 = { Az, Az }, Bx2 = { Bx, Bx }, By2 = { By, By }, Bz2 = { Bz, Bz };
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const vf2 bx = { (float)((nx >> (8 * k)) & 0xFFu), (float)((fx >> (8 * k)) & 0xFFu) };
+                        const vf2 by = { (float)((ny >> (8 * k)) & 0xFFu), (float)((fy >> (8 * k)) & 0xFFu) };
+                        const vf2 bz = { (float)((nz >> (8 * k)) & 0xFFu), (float)((fz >> (8 * k)) & 0xFFu) };
+                        const vf2 tx = __builtin_elementwise_fma(bx, Ax2, Bx2);
+                        const vf2 ty = __builtin_elementwise_fma(by, Ay2, By2);
+                        const vf2 tz = __builtin_elementwise_fma(bz, Az2, Bz2);
+                        const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
+                        const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, h.t));
+                        key[k] = tn <= tf ? tn : inf;
+                    }
+#else
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const float tnx = fmaf((float)((nx >> (8 * k)) & 0xFFu), Ax, Bx), tfx = fmaf((float)((fx >> (8 * k)) & 0xFFu), Ax, Bx);
@@ -477,6 +505,7 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                         const float tf = fminf(fminf(tfx, tfy), fminf(tfz, h.t));
                         key[k] = tn <= tf ? tn : inf;
                     }
+#endif
                     // sort the four (entry distance, child) pairs, nearest first
                     auto cswap = [&](int a, int b) {
                         const bool sw = key[b] < key[a];
