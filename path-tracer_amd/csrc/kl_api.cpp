@@ -239,6 +239,7 @@ FrameDev make_frame(const kl_ctx *c, uint32_t first_frame, uint32_t nslots) {
     f.eps = c->params.eps; f.max_dist = c->params.max_dist;
     f.ao_length = c->params.ao_length; f.hdri_strength = c->params.hdri_strength;
     f.nseg = KL_QUEUE_SEGMENTS; f.segcap = c->segcap;
+    fastdiv_make(std::max(c->npl, 1u), f.div_npl); fastdiv_make(c->width, f.div_width); fastdiv_make(c->band_rows, f.div_band);
     return f;
 }
 

@@ -39,9 +39,9 @@ __device__ __forceinline__ v3 ldv(const float *p) { return V(p[0], p[1], p[2]); 
 
 // local pixel -> global pixel for the row-band partition
 __device__ __forceinline__ void local_to_pixel(const FrameDev &f, uint32_t li, uint32_t &x, uint32_t &y) {
-    uint32_t ly = li / f.width;
+    uint32_t ly = fastdiv(li, f.div_width);
     x = li - ly * f.width;
-    uint32_t band = ly / f.band_rows;
+    uint32_t band = fastdiv(ly, f.div_band);
     y = (band * f.world + f.rank) * f.band_rows + (ly - band * f.band_rows);
 }
 
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_generate(FrameDev f, RayQueue q, uint32
     const float m = fmaxf(rx, ry);
     const v3 pos = ldv(f.pos), pc = ldv(f.pc), pu = ldv(f.pu), pv = ldv(f.pv);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        uint32_t slot = i / f.npl, li = i - slot * f.npl, x, y;
+        uint32_t slot = fastdiv(i, f.div_npl), li = i - slot * f.npl, x, y;
         local_to_pixel(f, li, x, y);
         float ux = (((float)x + 0.5f) - 1.0f - rx / 2.0f) / m;
         float uy = (((float)y + 0.5f) - 1.0f - ry / 2.0f) / m;
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
             o = V(od.x, od.y, od.z); d = V(od.w, d2.x, d2.y); thr = V(tp.x, tp.y, tp.z);
             path = __float_as_uint(tp.w);
             const float t = hr.x; const uint32_t ref = __float_as_uint(hr.y);
-            uint32_t slot = path / f.npl, li = path - slot * f.npl, px, py;
+            uint32_t slot = fastdiv(path, f.div_npl), li = path - slot * f.npl, px, py;
             local_to_pixel(f, li, px, py);
             f4 r = rand4(px, py, f.first_frame + slot);
             v3 col = V(0, 0, 0);

@@ -83,7 +83,17 @@ struct FrameDev {
     uint32_t max_bounces, max_frames;
     float eps, max_dist, ao_length, hdri_strength;
     uint32_t nseg, segcap;              // queue segmentation, see RayQueue
+    // division by npl, width and band_rows as multiply-high + add + shift (exact for dividends below 2^31)
+    uint32_t div_npl[2], div_width[2], div_band[2];
 };
+// n / d for n < 2^31 with {m, s} = fastdiv_make(d): s = ceil(log2 d), m = floor(2^(32+s) / d) + 1 - 2^32
+__host__ __device__ inline void fastdiv_make(uint32_t d, uint32_t out[2]) {
+    uint32_t s = 0;
+    while ((1ull << s) < d) s++;
+    out[0] = (uint32_t)((((unsigned long long)1 << (32 + s)) / d) + 1ull - (1ull << 32));
+    out[1] = s;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const uint32_t ms[2]) { return (__umulhi(n, ms[0]) + n) >> ms[1]; }
 
 // ---- wavefront queues -------------------------------------------------------------
 // One ray = 40 bytes over three arrays so that every access is a full-width vector load:
