@@ -1,0 +1,130 @@
+"""GPU suite at the benchmark's full sizes: properties that do not need the oracle to finish a whole image.
+
+1080p / one million triangles (BASELINE config 3) and 4K tiles (config 4): determinism, shards == whole, batch
+lanes == one stream, sample ranges == mean, plus the oracle on a few full-width rows. Config 5's ten-million-
+primitive mixed scene: upload, tree guarantees, tree == flat loop on sampled rays, a 4K frame renders finite.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+import klrender as kl
+import kloracle as ko
+from test_gpu_parity import assert_bitexact
+from test_gpu_scene import random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def million():
+    return kl.synth_scene(blobs=1000, tris_per_blob=1000, seed=1)
+
+
+def _setup(r, scene, textures, **params):
+    r.upload_scene(*scene)
+    r.upload_texture(kl.TEX_HDRI, textures["hdri"]); r.upload_texture(kl.TEX_ALBEDO, textures["albedo"])
+    r.update_params(max_bounces=8, max_frames=0, **params)
+
+
+def test_1080p_million_triangles_properties(million, textures):
+    w, h, n = 1920, 1080, 6
+    with kl.Renderer(w, h) as r:
+        _setup(r, million, textures)
+        r.render_frames(n)
+        full = r.read_accum()
+        cn = r.counters()
+        r.reset(); r.render_frames(n)
+        again = r.read_accum()
+        # small batches on one stream and on three: same image as one 6-frame batch
+        r.update_params(frames_in_flight=2, batch_lanes=1); r.reset(); r.render_frames(n)
+        one_lane = r.read_accum()
+        r.update_params(frames_in_flight=1, batch_lanes=3); r.reset(); r.render_frames(n)
+        three_lanes = r.read_accum()
+    assert cn.paths == w * h * n and cn.rays > 3 * cn.paths
+    assert np.isfinite(full).all() and (full[..., 3] == 1.0).all()
+    assert_bitexact(again, full, "second render of the same frames")
+    assert_bitexact(one_lane, full, "batches of 2 frames, one stream")
+    assert_bitexact(three_lanes, full, "batches of 1 frame, three streams")
+    # checksum of the image: printed so that two boxes can be compared by eye in the log
+    print("crc32 of the 1080p 6-frame mean: %08x" % zlib.crc32(full.tobytes()))
+
+    # two row-band shards stitch to the whole (config 4's partition at config 3's size)
+    out = np.zeros_like(full)
+    for rank in range(2):
+        with kl.Renderer(w, h) as r:
+            _setup(r, million, textures)
+            r.set_shard(rank, 2, 8)
+            r.render_frames(n)
+            rows = [y for y in range(h) if (y // 8) % 2 == rank]
+            out[rows] = r.read_accum()
+    assert_bitexact(out, full, "two row-band shards")
+
+    # sample ranges: three disjoint 2-frame sums add up to the 6-frame mean (fp32 re-association only)
+    total = np.zeros(full.shape, dtype=np.float64)
+    for g in range(3):
+        with kl.Renderer(w, h) as r:
+            _setup(r, million, textures)
+            r.set_accum_mode(kl.ACCUM_SUM)
+            r.render_frames(2, first_frame=2 * g)
+            total += r.read_accum()
+    assert np.allclose((total[..., :3] / n).astype(np.float32), full[..., :3], rtol=2e-5, atol=1e-6)
+
+
+def test_1080p_rows_against_the_oracle(million, textures):
+    """frame 0 of the full-size workload, three full-width row bands, bit for bit against the CPU oracle"""
+    w, h = 1920, 1080
+    with kl.Renderer(w, h) as r:
+        _setup(r, million, textures)
+        r.render_frames(1)
+        raw = r.read_raw()
+    sc = ko.Scene(*million)
+    sc.set_texture(ko.TEX_HDRI, textures["hdri"]); sc.set_texture(ko.TEX_ALBEDO, textures["albedo"])
+    p = ko.default_params(width=w, height=h, mode=ko.MODE_PT, max_frames=0, max_bounces=8, use_bvh=1)
+    for y0 in (0, 537, 1076):
+        want = sc.render_raw(ko.default_camera(), p, 0, rows=(y0, y0 + 4))
+        assert_bitexact(raw[y0:y0 + 4], want[y0:y0 + 4], "rows %d..%d" % (y0, y0 + 3))
+
+
+def test_4k_tiles_over_eight_ranks(million, textures):
+    """config 4's partition: 3840x2160 in 8-row bands over 8 ranks; every rank's rows equal the whole image's"""
+    w, h, n = 3840, 2160, 2
+    with kl.Renderer(w, h) as r:
+        _setup(r, million, textures)
+        r.render_frames(n)
+        full = r.read_accum()
+    assert np.isfinite(full).all()
+    for rank in (0, 3, 7):
+        with kl.Renderer(w, h) as r:
+            _setup(r, million, textures)
+            r.set_shard(rank, 8, 8)
+            r.render_frames(n)
+            rows = [y for y in range(h) if (y // 8) % 8 == rank]
+            assert r.local_rows == len(rows)
+            assert_bitexact(r.read_accum(), full[rows], "rank %d of 8" % rank)
+
+
+def test_ten_million_primitive_mixed_scene(textures):
+    """config 5's scene: 9990 blobs x 1000 triangles + 10000 analytic spheres in the seven-quad room"""
+    s, q, t, m = kl.synth_scene(blobs=9990, tris_per_blob=1000, analytic_spheres=10000, seed=1)
+    assert len(t) == 9_990_000 and len(s) == 10_000 and len(q) == 7
+    with kl.Renderer(3840, 2160) as r:
+        r.upload_scene(s, q, t, m)
+        st = r.bvh_stats()
+        assert (st.spheres, st.quads, st.tris) == (len(s), len(q), len(t))
+        assert st.max_depth <= 32 and 1 <= st.max_leaf_size <= 8 and st.node_bytes == st.nodes * 64
+        print("10 M primitives: %d nodes, build %.2f s, %d flat quads" % (st.nodes, st.build_seconds, st.flat_quads))
+        o, d = random_rays(192, 9)
+        tb, pb, ub = r.trace_rays(o, d)
+        r.update_params(accel=kl.ACCEL_BRUTE)            # 192 rays x 10 M primitives through the flat loop
+        tf, pf, uf = r.trace_rays(o, d)
+        assert np.array_equal(pb, pf)
+        assert_bitexact(tb, tf, "10 M primitives: tree vs flat loop, t")
+        assert_bitexact(ub, uf, "10 M primitives: tree vs flat loop, uv")
+        r.update_params(accel=kl.ACCEL_BVH, max_bounces=8, max_frames=0)
+        r.upload_texture(kl.TEX_HDRI, textures["hdri"]); r.upload_texture(kl.TEX_ALBEDO, textures["albedo"])
+        r.render_frames(1)
+        raw = r.read_raw()
+        cn = r.counters()
+    assert np.isfinite(raw).all() and raw[..., :3].max() > 0 and cn.paths == 3840 * 2160
