@@ -156,12 +156,26 @@ KL_API kl_status kl_get_frame(kl_ctx *ctx, uint32_t *frame);            /* iFram
 KL_API kl_status kl_upload_texture(kl_ctx *ctx, uint32_t which, const uint8_t *pixels,
                                    uint32_t width, uint32_t height, uint32_t channels);
 
+/* Float equirectangular environment, rgb or rgba rows as given, used in place of the 8-bit iHdri with the same
+ * lookup (RawFrame.glsl:330-339: NEAREST, clamp) and no 1/255 scaling. The role north_star's Background.exr was
+ * meant to play: the reference never loads it (GLSL_Renderer.cpp:237 loads Background.png). pixels = NULL goes
+ * back to the 8-bit texture. Resets the frame counter like every other input change. */
+KL_API kl_status kl_upload_env_float(kl_ctx *ctx, const float *pixels, uint32_t width, uint32_t height, uint32_t channels);
+
 /* -- scene: replaces the const arrays of RawFrame.glsl:171-192 -- */
 KL_API kl_status kl_upload_scene(kl_ctx *ctx, const kl_sphere *spheres, uint32_t n_spheres,
                                  const kl_quad *quads, uint32_t n_quads,
                                  const kl_tri *tris, uint32_t n_tris,
                                  const kl_material *materials, uint32_t n_materials);
 KL_API kl_status kl_load_builtin_scene(kl_ctx *ctx);                    /* RawFrame.glsl:171-192 */
+/* Scene ingestion (no loader in the reference; shaped after the CPU-side containers of include/Object/Mesh.h:5-26):
+ * reads a Wavefront .obj or a Stanford .ply (ascii or binary_little_endian) into a malloc'ed kl_tri array that the
+ * caller hands to kl_upload_scene and releases with kl_free. Polygons become triangle fans; per-corner texture
+ * coordinates are kept; in an .obj the k-th distinct `usemtl` name selects material index `material + k` (clamped
+ * to n_materials - 1 when n_materials != 0). Needs no context and no GPU. kl_load_mesh_error() = what was wrong. */
+KL_API kl_status kl_load_mesh(const char *path, uint32_t material, uint32_t n_materials, kl_tri **tris, uint32_t *n_tris);
+KL_API const char *kl_load_mesh_error(void);
+KL_API void kl_free(void *p);
 KL_API kl_status kl_get_bvh_stats(kl_ctx *ctx, kl_bvh_stats *out);
 /* synthetic benchmark scene (no reference counterpart): sizes first, then fill caller-owned arrays */
 KL_API kl_status kl_synth_scene_counts(const kl_synth_params *sp, uint32_t *n_spheres, uint32_t *n_quads,
@@ -173,6 +187,13 @@ KL_API kl_status kl_synth_scene_fill(const kl_synth_params *sp, kl_sphere *spher
  *    first_frame = KL_CONTINUE continues from the context's frame counter -- */
 KL_API kl_status kl_render_frames(kl_ctx *ctx, uint32_t n, uint32_t first_frame);
 KL_API kl_status kl_synchronize(kl_ctx *ctx);
+
+/* -- accumulation checkpoint (no reference counterpart: the reference restarts from iFrame = 0): writes / reads
+ *    {image size and shard, frame counter, view mode, camera, parameters, accumulation, last raw frame}. After a
+ *    load into a context of the same size and shard, kl_render_frames(KL_CONTINUE) carries on bit for bit as the
+ *    saved session would have. Scene and textures are not part of the file. -- */
+KL_API kl_status kl_checkpoint_save(kl_ctx *ctx, const char *path);
+KL_API kl_status kl_checkpoint_load(kl_ctx *ctx, const char *path);
 
 /* -- results: what raw_frame_tex / accumulation_tex hold (GLSL_Renderer.cpp:223-234), float RGBA,
  *    row 0 = bottom row (gl_FragCoord.y = 0.5); and pass 3, PostProcess.glsl:34-39 -- */

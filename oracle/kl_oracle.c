@@ -184,6 +184,7 @@ struct ko_scene {
     ko_tri *tris; uint32_t nt;
     ko_material *mats; uint32_t nm;
     uint8_t *tex[2]; uint32_t tw[2], th[2];   /* RGBA8 */
+    float *envf; uint32_t envf_w, envf_h;     /* optional float RGB environment (no reference counterpart), replaces tex[HDRI] */
     ko_node *nodes; uint32_t nnodes; uint32_t *order;  /* BVH over global primitive ids */
 };
 
@@ -290,7 +291,7 @@ ko_scene *ko_scene_create(const ko_sphere *sp, uint32_t ns, const ko_quad *q, ui
 void ko_scene_destroy(ko_scene *s) {
     if (!s) return;
     free(s->spheres); free(s->quads); free(s->tris); free(s->mats);
-    free(s->tex[0]); free(s->tex[1]); free(s->nodes); free(s->order); free(s);
+    free(s->tex[0]); free(s->tex[1]); free(s->envf); free(s->nodes); free(s->order); free(s);
 }
 /* source/I-O/File.cpp:13-29 + source/Rendering/Opengl/Texture.cpp:8-12:
  * 8-bit, 1/3/4 channels, no flip; stored here expanded to RGBA8 */
@@ -303,6 +304,19 @@ int ko_scene_set_texture(ko_scene *s, int which, const uint8_t *px, uint32_t w, 
         else { d[4*i] = px[i]; d[4*i+1] = 0; d[4*i+2] = 0; d[4*i+3] = 255; } /* GL_RED upload: g=b=0 */
     }
     free(s->tex[which]); s->tex[which] = d; s->tw[which] = w; s->th[which] = h;
+    return 0;
+}
+
+/* Float equirectangular environment (the role Background.exr was meant to play; the reference never loads
+ * it). Same lookup as the 8-bit one: NEAREST, clamp, rows as given; the texel is used as it is, times
+ * HDRI_STRENGTH. channels = 3 or 4 (alpha ignored); px = NULL goes back to the 8-bit texture. */
+int ko_scene_set_env_float(ko_scene *s, const float *px, uint32_t w, uint32_t h, uint32_t ch) {
+    if (!s) return -1;
+    if (!px) { free(s->envf); s->envf = NULL; s->envf_w = s->envf_h = 0; return 0; }
+    if (!w || !h || (ch != 3 && ch != 4)) return -1;
+    float *d = (float *)malloc((size_t)w * h * 3 * sizeof(float));
+    for (size_t i = 0; i < (size_t)w * h; i++) { d[3*i] = px[ch*i]; d[3*i+1] = px[ch*i+1]; d[3*i+2] = px[ch*i+2]; }
+    free(s->envf); s->envf = d; s->envf_w = w; s->envf_h = h;
     return 0;
 }
 
@@ -566,6 +580,14 @@ void ko_env_uv(const float d[3], float uv[2]) {
 static v3 environment(const ko_scene *s, const ko_params *p, v3 d) {
     float uv[2];
     ko_env_uv(&d.x, uv);
+    if (s->envf) {
+        uint32_t w = s->envf_w, h = s->envf_h;
+        float fx = floorf(uv[0] * (float)w), fy = floorf(uv[1] * (float)h);
+        uint32_t ix = !(fx >= 0.0f) ? 0u : (fx >= (float)w ? w - 1 : (uint32_t)fx);
+        uint32_t iy = !(fy >= 0.0f) ? 0u : (fy >= (float)h ? h - 1 : (uint32_t)fy);
+        const float *px = s->envf + 3 * ((size_t)iy * w + ix);
+        return vscale(V(px[0], px[1], px[2]), p->hdri_strength);
+    }
     return vscale(tex_fetch(s, KO_TEX_HDRI, uv[0], uv[1]), p->hdri_strength); /* RF:338 */
 }
 

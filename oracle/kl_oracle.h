@@ -59,6 +59,8 @@ ko_scene *ko_scene_create(const ko_sphere *s, uint32_t ns, const ko_quad *q, uin
 ko_scene *ko_scene_builtin(void);        /* RawFrame.glsl:171-192 */
 void ko_scene_destroy(ko_scene *s);
 int ko_scene_set_texture(ko_scene *s, int which, const uint8_t *pixels, uint32_t w, uint32_t h, uint32_t channels);
+/* float RGB(A) equirectangular environment in place of the 8-bit one (NULL: back to 8-bit) */
+int ko_scene_set_env_float(ko_scene *s, const float *pixels, uint32_t w, uint32_t h, uint32_t channels);
 
 /* Renders rows [y0,y1) of one raw frame into rgba (full-image layout,
  * row 0 = bottom row = gl_FragCoord.y 0.5). last_acc supplies the

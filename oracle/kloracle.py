@@ -55,6 +55,7 @@ def lib():
         L.ko_scene_builtin.restype = C.c_void_p
         L.ko_scene_destroy.argtypes = [C.c_void_p]
         L.ko_scene_set_texture.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.ko_scene_set_env_float.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.ko_render_raw.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
         L.ko_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int]
@@ -119,6 +120,15 @@ class Scene:
         h, w, ch = px.shape
         if lib().ko_scene_set_texture(self.h, which, _ptr(px), w, h, ch) != 0:
             raise ValueError("bad texture")
+
+    def set_env_float(self, pixels):
+        if pixels is None:
+            lib().ko_scene_set_env_float(self.h, None, 0, 0, 0)
+            return
+        px = np.ascontiguousarray(pixels, dtype=np.float32)
+        h, w, ch = px.shape
+        if lib().ko_scene_set_env_float(self.h, _ptr(px), w, h, ch) != 0:
+            raise ValueError("bad float environment")
 
     def render_raw(self, cam, params, frame, last_acc=None, rows=None, nthreads=None, counters=None):
         w, h = params.width, params.height

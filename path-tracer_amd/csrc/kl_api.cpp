@@ -77,6 +77,7 @@ struct kl_ctx {
     kl_bvh_stats bvh_stats;
     DevBuf<float4> d_rec, d_tri_uv, d_mats, d_flatq;
     DevBuf<uchar4> d_tex[2];
+    DevBuf<float4> d_envf;
     // wavefront state
     uint32_t slots = 0;               // frames in flight the buffers are sized for
     uint32_t slots_npl = 0;           // ... at this many pixels
@@ -377,6 +378,7 @@ kl_status kl_destroy(kl_ctx *c) {
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
     c->d_rec.release(); c->d_tri_uv.release(); c->d_mats.release(); c->d_flatq.release();
     for (int k = 0; k < 2; k++) c->d_tex[k].release();
+    c->d_envf.release();
     for (uint32_t l = 0; l < KL_MAX_BATCH_LANES; l++) {
         BatchLane &L = c->lanes[l];
         if (l > 0 && L.stream) { (void)hipStreamSynchronize(L.stream); (void)hipStreamDestroy(L.stream); }
@@ -449,6 +451,25 @@ kl_status kl_upload_texture(kl_ctx *c, uint32_t which, const uint8_t *px, uint32
     KL_HIP(c, hipMemcpy(c->d_tex[which].p, tmp.data(), n * sizeof(uchar4), hipMemcpyHostToDevice));
     c->sc.tex[which] = c->d_tex[which].p; c->sc.tex_w[which] = w; c->sc.tex_h[which] = h;
     return KL_OK;
+}
+
+kl_status kl_upload_env_float(kl_ctx *c, const float *px, uint32_t w, uint32_t h, uint32_t ch) {
+    if (!c) return KL_E_INVALID;
+    KL_HIP(c, hipSetDevice(c->device));
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    if (!px) {                                   // back to the 8-bit environment
+        c->d_envf.release(); c->sc.envf = nullptr; c->sc.envf_w = c->sc.envf_h = 0;
+        return kl_reset(c);
+    }
+    if (!w || !h || w > KL_MAX_DIM || h > KL_MAX_DIM || (ch != 3 && ch != 4))
+        return fail(c, KL_E_INVALID, "float environment must have 3 or 4 channels");
+    const size_t n = (size_t)w * h;
+    std::vector<float4> tmp(n);
+    for (size_t i = 0; i < n; i++) tmp[i] = make_float4(px[ch * i], px[ch * i + 1], px[ch * i + 2], 1.0f);
+    KL_HIP(c, c->d_envf.alloc(n));
+    KL_HIP(c, hipMemcpy(c->d_envf.p, tmp.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    c->sc.envf = c->d_envf.p; c->sc.envf_w = w; c->sc.envf_h = h;
+    return kl_reset(c);
 }
 
 kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq,
@@ -788,6 +809,70 @@ kl_status kl_copy_accum_from_device(kl_ctx *c, const void *src, size_t bytes) {
     if (bytes != (size_t)c->npl * 16) return fail(c, KL_E_INVALID, "size must be local_rows x width x 16 bytes");
     KL_HIP(c, hipMemcpyAsync(c->d_acc.p, src, bytes, hipMemcpyDeviceToDevice, c->stream));
     KL_HIP(c, hipStreamSynchronize(c->stream));
+    return KL_OK;
+}
+
+// ---- accumulation checkpoint: header + accumulation + last raw frame, little-endian as in memory ----
+namespace {
+struct CkHeader {
+    char magic[8];                 // "KLCKPT1\0"
+    uint32_t width, height, rank, world, band_rows, local_rows;
+    uint32_t frame, mode, accum_mode, camera_change;
+    kl_camera cam;
+    kl_params params;
+    uint64_t texels;               // local_rows * width
+};
+}  // namespace
+
+kl_status kl_checkpoint_save(kl_ctx *c, const char *path) {
+    if (!c || !path) return fail(c, KL_E_INVALID, "null path");
+    if (!c->d_acc.p || c->d_acc.n != c->npl || !c->npl) return fail(c, KL_E_STATE, "nothing rendered yet");
+    KL_HIP(c, hipSetDevice(c->device));
+    std::vector<float4> acc(c->npl), raw(c->npl);
+    KL_HIP(c, hipMemcpyAsync(acc.data(), c->d_acc.p, c->npl * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    KL_HIP(c, hipMemcpyAsync(raw.data(), c->d_last_raw.p, c->npl * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    CkHeader hd; std::memset(&hd, 0, sizeof hd);
+    std::memcpy(hd.magic, "KLCKPT1", 8);
+    hd.width = c->width; hd.height = c->height; hd.rank = c->rank; hd.world = c->world; hd.band_rows = c->band_rows;
+    hd.local_rows = c->local_rows; hd.frame = c->frame; hd.mode = c->mode; hd.accum_mode = c->accum_mode;
+    hd.camera_change = c->camera_change ? 1u : 0u; hd.cam = c->cam; hd.params = c->params; hd.texels = c->npl;
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return fail(c, KL_E_INVALID, std::string("cannot write ") + path);
+    bool ok = std::fwrite(&hd, sizeof hd, 1, fp) == 1 && std::fwrite(acc.data(), sizeof(float4), acc.size(), fp) == acc.size() &&
+              std::fwrite(raw.data(), sizeof(float4), raw.size(), fp) == raw.size();
+    ok = (std::fclose(fp) == 0) && ok;
+    return ok ? KL_OK : fail(c, KL_E_INVALID, std::string("short write to ") + path);
+}
+
+kl_status kl_checkpoint_load(kl_ctx *c, const char *path) {
+    if (!c || !path) return fail(c, KL_E_INVALID, "null path");
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return fail(c, KL_E_INVALID, std::string("cannot read ") + path);
+    CkHeader hd;
+    if (std::fread(&hd, sizeof hd, 1, fp) != 1 || std::memcmp(hd.magic, "KLCKPT1", 8) != 0) {
+        std::fclose(fp); return fail(c, KL_E_INVALID, "not a checkpoint file");
+    }
+    // the image, its partition and the view mode must be the context's; camera and parameters are restored
+    if (hd.width != c->width || hd.height != c->height || hd.rank != c->rank || hd.world != c->world ||
+        hd.band_rows != c->band_rows || hd.local_rows != c->local_rows || hd.texels != c->npl) {
+        std::fclose(fp); return fail(c, KL_E_STATE, "checkpoint was written for another image size or shard");
+    }
+    if (hd.mode > KL_MODE_Z || hd.accum_mode > KL_ACCUM_SUM) { std::fclose(fp); return fail(c, KL_E_INVALID, "corrupt checkpoint header"); }
+    std::vector<float4> acc(c->npl), raw(c->npl);
+    bool ok = std::fread(acc.data(), sizeof(float4), acc.size(), fp) == acc.size() &&
+              std::fread(raw.data(), sizeof(float4), raw.size(), fp) == raw.size();
+    std::fclose(fp);
+    if (!ok) return fail(c, KL_E_INVALID, "truncated checkpoint");
+    kl_status s = kl_set_params(c, &hd.params);
+    if (s != KL_OK) return s;
+    s = ensure_buffers(c);
+    if (s != KL_OK) return s;
+    KL_HIP(c, hipMemcpyAsync(c->d_acc.p, acc.data(), c->npl * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    KL_HIP(c, hipMemcpyAsync(c->d_last_raw.p, raw.data(), c->npl * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    c->cam = hd.cam; c->mode = hd.mode; c->accum_mode = hd.accum_mode;
+    c->frame = hd.frame; c->camera_change = hd.camera_change != 0;
     return KL_OK;
 }
 

@@ -648,6 +648,14 @@ __device__ __forceinline__ v3 environment(const SceneDev &sc, const FrameDev &f,
     float theta = acosf_(rz);
     float u = phi / 6.28318530718f + 0.5f;
     float v = theta / 3.14159265359f;
+    if (sc.envf) {            // float environment: same NEAREST / clamp lookup, the texel as it is
+        const uint32_t w = sc.envf_w, hgt = sc.envf_h;
+        const float fx = floorf(u * (float)w), fy = floorf(v * (float)hgt);
+        const uint32_t ix = !(fx >= 0.0f) ? 0u : (fx >= (float)w ? w - 1u : (uint32_t)fx);
+        const uint32_t iy = !(fy >= 0.0f) ? 0u : (fy >= (float)hgt ? hgt - 1u : (uint32_t)fy);
+        const float4 px = sc.envf[(size_t)iy * w + ix];
+        return V(px.x, px.y, px.z) * f.hdri_strength;
+    }
     return tex_fetch(sc, KL_TEX_HDRI, u, v) * f.hdri_strength;
 }
 // RF:273-277

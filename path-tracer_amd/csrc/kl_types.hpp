@@ -70,6 +70,9 @@ struct SceneDev {
     // textures, RGBA8, rows as uploaded
     const uchar4 *tex[2];
     uint32_t tex_w[2], tex_h[2];
+    // optional float environment (rgb in xyz), used instead of tex[KL_TEX_HDRI] when not null
+    const float4 *envf;
+    uint32_t envf_w, envf_h;
 };
 
 // ---- per-batch uniforms ---------------------------------------------------------

@@ -101,6 +101,12 @@ SIGNATURES = {
     "kl_set_accum_mode": (C.c_int32, [_P, C.c_uint32]),
     "kl_copy_accum_to_device": (C.c_int32, [_P, _P, C.c_size_t]),
     "kl_copy_accum_from_device": (C.c_int32, [_P, _P, C.c_size_t]),
+    "kl_upload_env_float": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "kl_load_mesh": (C.c_int32, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint32)]),
+    "kl_load_mesh_error": (C.c_char_p, []),
+    "kl_free": (None, [_P]),
+    "kl_checkpoint_save": (C.c_int32, [_P, C.c_char_p]),
+    "kl_checkpoint_load": (C.c_int32, [_P, C.c_char_p]),
     "kl_status_string": (C.c_char_p, [C.c_int32]),
     "kl_last_error": (C.c_char_p, [_P]),
     "kl_abi_version": (C.c_uint32, []),
@@ -160,6 +166,22 @@ def synth_scene(blobs, tris_per_blob=1000, analytic_spheres=0, seed=1):
     if rc != 0:
         raise KlError("kl_synth_scene_fill: %s" % lib().kl_status_string(rc).decode())
     return s, q, t, m
+
+
+def load_mesh(path, material=0, n_materials=0):
+    """Triangles of a Wavefront .obj or Stanford .ply file as a tri_dtype array (kl_load_mesh)."""
+    buf = _P()
+    n = C.c_uint32()
+    rc = lib().kl_load_mesh(os.fsencode(path), material, n_materials, C.byref(buf), C.byref(n))
+    if rc != 0:
+        raise KlError("kl_load_mesh: %s (%s)" % (lib().kl_status_string(rc).decode(), lib().kl_load_mesh_error().decode()))
+    try:
+        out = np.zeros(n.value, dtype=tri_dtype)
+        if n.value:
+            C.memmove(out.ctypes.data, buf, out.nbytes)
+    finally:
+        lib().kl_free(buf)
+    return out
 
 
 class Renderer:
@@ -290,6 +312,21 @@ class Renderer:
 
     def reset_counters(self):
         self._ck(lib().kl_reset_counters(self._h), "kl_reset_counters")
+
+    def upload_env_float(self, pixels):
+        """float rgb(a) equirectangular environment in place of the 8-bit one (None: back to 8-bit)"""
+        if pixels is None:
+            self._ck(lib().kl_upload_env_float(self._h, None, 0, 0, 0), "kl_upload_env_float")
+            return
+        px = np.ascontiguousarray(pixels, dtype=np.float32)
+        h, w, ch = px.shape
+        self._ck(lib().kl_upload_env_float(self._h, _ptr(px), w, h, ch), "kl_upload_env_float")
+
+    def save_checkpoint(self, path):
+        self._ck(lib().kl_checkpoint_save(self._h, os.fsencode(path)), "kl_checkpoint_save")
+
+    def load_checkpoint(self, path):
+        self._ck(lib().kl_checkpoint_load(self._h, os.fsencode(path)), "kl_checkpoint_load")
 
     def timing(self):
         t = Timing()
