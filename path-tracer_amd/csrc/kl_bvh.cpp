@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <limits>
@@ -35,7 +36,10 @@ struct TmpNode {
 struct TmpLeaf { uint32_t type, start, count; };   // range in Builder::prims
 
 constexpr int NBINS = 16;
-constexpr uint32_t LEAF_TARGET = 4;
+// tuning knobs of the builder (environment overrides are for experiments): runs of at most leaf_target
+// primitives become a leaf without asking the SAH; trav_cost = cost of one binary node visit relative to one primitive test
+static uint32_t LEAF_TARGET = 2;
+static float TRAV_COST = 1.0f;
 
 struct Builder {
     std::vector<Prim> prims;
@@ -110,7 +114,7 @@ struct Builder {
                     if (n <= LEAF_MAX && homo) {
                         // SAH termination: leaf cost n*A against one node visit plus the children
                         float pa = bounds(b, e).area();
-                        if ((float)n * pa <= pa + best_cost) return make_leaf(b, e);
+                        if ((float)n * pa <= TRAV_COST * pa + best_cost) return make_leaf(b, e);
                     }
                     const float scale = (float)NBINS / ext[best_axis];
                     const float lo = cb.lo[best_axis];
@@ -257,6 +261,8 @@ void identity_order(uint32_t ns, uint32_t nq, uint32_t nt, HostBVH &out) {
 void build_bvh(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
                HostBVH &out, unsigned threads, float flat_fraction, uint32_t max_flat) {
     auto t0 = std::chrono::steady_clock::now();
+    if (const char *e = std::getenv("KL_BVH_LEAF_TARGET")) LEAF_TARGET = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
+    if (const char *e = std::getenv("KL_BVH_TRAV_COST")) TRAV_COST = (float)std::atof(e);
     uint32_t n = ns + nq + nt;
     identity_order(0, 0, 0, out);
     out.stats.spheres = ns; out.stats.quads = nq; out.stats.tris = nt;
