@@ -104,17 +104,24 @@ def main():
     import klrender as kl
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU. Rehearsal on a box with fewer GPUs than ranks: KL_BENCH_BACKEND=gloo lets several
+    # ranks share a device (RCCL refuses that), everything else being the same code path.
+    backend = os.environ.get("KL_BENCH_BACKEND", "nccl")
+    device = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     bg, tx, tex_note = load_textures()
     scene = kl.synth_scene(blobs=args.blobs, tris_per_blob=args.tris_per_blob, seed=1)
     n_tris = len(scene[2])
-    r = kl.Renderer(args.width, args.height, device=local_rank)
+    r = kl.Renderer(args.width, args.height, device=device)
     r.upload_scene(*scene)
     r.upload_texture(kl.TEX_HDRI, bg)
     r.upload_texture(kl.TEX_ALBEDO, tx)
@@ -235,7 +242,7 @@ def main():
                        "bvh_build_s": round(bvh.build_seconds, 3), "frames_in_flight": int(r.get_params().frames_in_flight),
                        "textures": tex_note,
                        "partition": "single GPU, running mean" if world == 1 else
-                                    "sample ranges: %d frames per rank, RCCL all-reduce(sum) per step" % args.spp},
+                                    "sample ranges: %d frames per rank, %s all-reduce(sum) per step" % (args.spp, "RCCL" if backend == "nccl" else backend)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
