@@ -93,7 +93,10 @@ typedef struct kl_params {
     uint32_t profile_kernels;  /* 1: HIP events around every intersect launch, see kl_get_timing */
     uint32_t batch_lanes;      /* batches traced concurrently on separate HIP streams, each with its own queues: 0 = choose
                                   (2 while batches are small, else 1), 1 = one stream, at most 4. The image does not depend on it (batches accumulate in frame order). */
-    uint32_t reserved[4];
+    uint32_t trace_primary_per_frame; /* 0: the camera ray of a pixel, which is the same in every frame (RawFrame.glsl:436 adds no
+                                  jitter at SPP = 1), is traced once per batch and its hit shared by the batch's frames;
+                                  1: traced again for every frame, as the shader does. The image is the same either way. */
+    uint32_t reserved[3];
 } kl_params;
 
 typedef struct kl_counters {

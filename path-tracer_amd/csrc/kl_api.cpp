@@ -49,12 +49,15 @@ struct BatchLane {
     hipStream_t stream = nullptr;
     DevBuf<float4> d_od[2], d_tp[2], d_hits, d_raw;
     DevBuf<float2> d_d2[2];
+    DevBuf<float4> p_od, p_hits;      // one-frame queue of the camera rays and their hits, shared by the frames of a batch
+    DevBuf<float2> p_d2;
     DevBuf<uint32_t> d_qctl;          // count[0..B], head[0..B]
     DevBuf<int> d_overflow;           // traversal stack entries beyond the LDS part
     hipEvent_t done = nullptr;        // recorded after the lane's latest accumulate
     void release() {
         for (int k = 0; k < 2; k++) { d_od[k].release(); d_d2[k].release(); d_tp[k].release(); }
         d_hits.release(); d_raw.release(); d_qctl.release(); d_overflow.release();
+        p_od.release(); p_hits.release(); p_d2.release();
     }
 };
 
@@ -83,6 +86,7 @@ struct kl_ctx {
     uint32_t slots_npl = 0;           // ... at this many pixels
     uint32_t auto_slots = 0, auto_slots_npl = 0;   // automatic batch size, decided once per image size
     uint32_t segcap = 0;              // entries per queue segment
+    uint32_t segcap1 = 0;             // ... of the one-frame camera-ray queue
     // Batches are independent until they accumulate, so consecutive batches run on different HIP streams
     // ("lanes"), each with its own queues: while one batch drains the long tail of a traversal launch, the
     // next one already fills the CUs that fell idle. Lane 0 is the context's own stream.
@@ -167,6 +171,8 @@ kl_status ensure_buffers(kl_ctx *c, uint32_t lanes = 1, uint32_t frames = 1) {
     const size_t groups = (cap + 63) / 64;
     c->segcap = (uint32_t)((groups + KL_QUEUE_SEGMENTS - 1) / KL_QUEUE_SEGMENTS * 64);
     const size_t qcap = (size_t)c->segcap * KL_QUEUE_SEGMENTS;
+    c->segcap1 = (uint32_t)((((size_t)c->npl + 63) / 64 + KL_QUEUE_SEGMENTS - 1) / KL_QUEUE_SEGMENTS * 64);
+    const size_t qcap1 = std::max<size_t>((size_t)c->segcap1 * KL_QUEUE_SEGMENTS, 1);
     lanes = std::max(1u, std::min(lanes, KL_MAX_BATCH_LANES));
     for (uint32_t l = 0; l < lanes; l++) {
         BatchLane &L = c->lanes[l];
@@ -180,7 +186,8 @@ kl_status ensure_buffers(kl_ctx *c, uint32_t lanes = 1, uint32_t frames = 1) {
         }
         KL_HIP(c, L.d_hits.alloc(qcap));
         KL_HIP(c, L.d_raw.alloc(cap));
-        KL_HIP(c, L.d_qctl.alloc(2 * ((size_t)c->params.max_bounces + 2) * KL_QUEUE_SEGMENTS * CTR_STRIDE));
+        KL_HIP(c, L.d_qctl.alloc(2 * ((size_t)c->params.max_bounces + 3) * KL_QUEUE_SEGMENTS * CTR_STRIDE));
+        KL_HIP(c, L.p_od.alloc(qcap1)); KL_HIP(c, L.p_d2.alloc(qcap1)); KL_HIP(c, L.p_hits.alloc(qcap1));
         KL_HIP(c, L.d_overflow.alloc(intersect_overflow_ints(c->lc)));
     }
     c->n_lanes = std::max(c->n_lanes, lanes);
@@ -251,18 +258,18 @@ bool use_bvh(const kl_ctx *c) {
     return c->n_prims > KL_BRUTE_AUTO_LIMIT;
 }
 
-kl_status timed_intersect(kl_ctx *c, BatchLane &L, const FrameDev &f, RayQueue q, uint32_t *count, uint32_t *head, uint32_t max_rays) {
+kl_status timed_intersect(kl_ctx *c, BatchLane &L, const FrameDev &f, RayQueue q, float4 *hits, uint32_t *count, uint32_t *head, uint32_t max_rays) {
     hipEvent_t a = nullptr, b = nullptr;
     const bool bvh = use_bvh(c);
     if (bvh && scene_has_flat(c->sc))
-        launch_intersect_flat(L.stream, c->lc, c->sc, f, q, L.d_hits.p, count, c->d_counters.p, c->params.collect_stats != 0, max_rays);
+        launch_intersect_flat(L.stream, c->lc, c->sc, f, q, hits, count, c->d_counters.p, c->params.collect_stats != 0, max_rays);
     // the events bracket the dominant kernel only (k_intersect_bvh, or the flat loop for small scenes)
     if (c->params.profile_kernels) {
         if (c->pending.size() >= KL_MAX_PENDING_EVENTS) drain_events(c);
         a = get_event(c); b = get_event(c);
         if (a && b) KL_HIP(c, hipEventRecord(a, L.stream));
     }
-    launch_intersect(L.stream, c->lc, c->sc, f, q, L.d_hits.p, count, head, c->d_counters.p, L.d_overflow.p, bvh,
+    launch_intersect(L.stream, c->lc, c->sc, f, q, hits, count, head, c->d_counters.p, L.d_overflow.p, bvh,
                      c->params.collect_stats != 0, max_rays);
     if (a && b) { KL_HIP(c, hipEventRecord(b, L.stream)); c->pending.push_back({a, b, 0}); }
     return KL_OK;
@@ -275,18 +282,35 @@ kl_status render_batch(kl_ctx *c, BatchLane &L, hipEvent_t after, uint32_t first
     const uint32_t B = c->params.max_bounces;
     // count[b] / head[b]: one word per queue segment and bounce
     const size_t S = (size_t)KL_QUEUE_SEGMENTS * CTR_STRIDE;      // words per bounce level
-    uint32_t *count = L.d_qctl.p, *head = L.d_qctl.p + (size_t)(B + 2) * S;
+    uint32_t *count = L.d_qctl.p, *head = L.d_qctl.p + (size_t)(B + 3) * S;
     const uint32_t max_rays = nslots * c->npl;
     RayQueue q[2] = { {L.d_od[0].p, L.d_d2[0].p, L.d_tp[0].p}, {L.d_od[1].p, L.d_d2[1].p, L.d_tp[1].p} };
     const bool fused = c->params.fused_compaction != 0;
     const uint32_t levels = c->mode == KL_MODE_PT ? B : (c->mode == KL_MODE_AO ? 2u : 1u);
     KL_HIP(c, hipMemsetAsync(count, 0, (size_t)(levels + 1) * S * sizeof(uint32_t), L.stream));
     KL_HIP(c, hipMemsetAsync(head, 0, (size_t)(levels + 1) * S * sizeof(uint32_t), L.stream));
-    launch_generate(L.stream, c->lc, f, q[0], count);
+    // Every frame of the batch starts with the same camera ray per pixel: unless told otherwise, that ray is traced
+    // once (a one-frame queue of its own) and generate copies its hit to the paths of all frames.
+    const bool shared = nslots > 1 && c->params.trace_primary_per_frame == 0;
+    if (shared) {
+        FrameDev f1 = f; f1.nslots = 1; f1.segcap = c->segcap1;
+        uint32_t *count1 = count + (size_t)(B + 2) * S, *head1 = head + (size_t)(B + 2) * S;
+        KL_HIP(c, hipMemsetAsync(count1, 0, S * sizeof(uint32_t), L.stream));
+        KL_HIP(c, hipMemsetAsync(head1, 0, S * sizeof(uint32_t), L.stream));
+        RayQueue q1 = { L.p_od.p, L.p_d2.p, nullptr };
+        launch_generate(L.stream, c->lc, f1, q1, count1);
+        kl_status s1 = timed_intersect(c, L, f1, q1, L.p_hits.p, count1, head1, c->npl);
+        if (s1 != KL_OK) return s1;
+        launch_generate(L.stream, c->lc, f, q[0], count, L.p_hits.p, c->segcap1, L.d_hits.p);
+    } else {
+        launch_generate(L.stream, c->lc, f, q[0], count);
+    }
     for (uint32_t b = 0; b < levels; b++) {
         RayQueue qi = q[b & 1u], qo = q[(b + 1u) & 1u];
-        kl_status s = timed_intersect(c, L, f, qi, count + (size_t)b * S, head + (size_t)b * S, max_rays);
-        if (s != KL_OK) return s;
+        if (!(shared && b == 0)) {
+            kl_status s = timed_intersect(c, L, f, qi, L.d_hits.p, count + (size_t)b * S, head + (size_t)b * S, max_rays);
+            if (s != KL_OK) return s;
+        }
         launch_shade(L.stream, c->lc, c->sc, f, qi, L.d_hits.p, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, L.d_raw.p, b, fused, max_rays);
         if (!fused && b + 1 < levels) launch_compact(L.stream, c->lc, f, qi, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, max_rays);
     }
@@ -326,7 +350,7 @@ kl_status kl_default_params(kl_params *p) {
     std::memset(p, 0, sizeof *p);
     p->max_bounces = 32; p->max_frames = 30; p->eps = 0.001f; p->max_dist = 5000.0f;
     p->ao_length = 1.0f; p->hdri_strength = 1.0f; p->accel = KL_ACCEL_AUTO;
-    p->frames_in_flight = 0; p->fused_compaction = 1; p->collect_stats = 0; p->profile_kernels = 0; p->batch_lanes = 0;
+    p->frames_in_flight = 0; p->fused_compaction = 1; p->collect_stats = 0; p->profile_kernels = 0; p->batch_lanes = 0; p->trace_primary_per_frame = 0;
     return KL_OK;
 }
 kl_status kl_default_camera(kl_camera *cam) {

@@ -165,7 +165,11 @@ __device__ __forceinline__ bool ray_finite(v3 o, v3 d) {
 
 // ------------------------------------------------------------------ generate
 // RF:417-422 with the uv arithmetic of RF:428-429,436; one thread per (slot, pixel)
-__global__ __launch_bounds__(256) void k_generate(FrameDev f, RayQueue q, uint32_t *count0) {
+// With `seed_hits`: every frame of a batch starts with the same camera ray per pixel (the shader adds no sub-pixel
+// jitter, RF:436 with SPP = 1), so the closest hit of that ray was found once, for a one-frame queue of segment
+// capacity `seed_segcap`, and is copied here into the hit record of each frame's path.
+__global__ __launch_bounds__(256) void k_generate(FrameDev f, RayQueue q, uint32_t *count0, const float4 *seed_hits,
+                                                  uint32_t seed_segcap, float4 *hits) {
     const uint32_t total = f.nslots * f.npl;
     const uint32_t groups = (total + 63u) >> 6;            // 64-path groups, dealt round-robin over the segments
     if (blockIdx.x == 0) {
@@ -194,7 +198,11 @@ __global__ __launch_bounds__(256) void k_generate(FrameDev f, RayQueue q, uint32
         const uint32_t dst = (g % f.nseg) * f.segcap + (g / f.nseg) * 64u + (i & 63u);
         q.od[dst] = make_float4(pos.x, pos.y, pos.z, d.x);
         q.d2[dst] = make_float2(d.y, d.z);
-        q.tp[dst] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(i));
+        if (q.tp) q.tp[dst] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(i));
+        if (seed_hits) {
+            const uint32_t g0 = li >> 6;         // where generate put this pixel's ray in the one-frame queue
+            hits[dst] = seed_hits[(g0 % f.nseg) * seed_segcap + (g0 / f.nseg) * 64u + (li & 63u)];
+        }
     }
 }
 
@@ -904,8 +912,9 @@ static inline uint32_t seg_grid(const FrameDev &f, uint32_t max_rays, uint32_t c
     return per_seg * f.nseg;
 }
 
-void launch_generate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue q, uint32_t *count0) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(f.nslots * f.npl, lc.cus * 8u)), dim3(256), 0, s, f, q, count0);
+void launch_generate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue q, uint32_t *count0,
+                     const float4 *seed_hits, uint32_t seed_segcap, float4 *hits) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(f.nslots * f.npl, lc.cus * 8u)), dim3(256), 0, s, f, q, count0, seed_hits, seed_segcap, hits);
 }
 size_t intersect_overflow_ints(const LaunchCfg &lc) {
     return (size_t)lc.cus * lc.isect_blocks_per_cu * ISECT_WAVES * ISECT_OVF_STACK * 64u;

@@ -11,7 +11,10 @@ struct LaunchCfg {
     uint32_t isect_blocks_per_cu;    // resident traversal workgroups per CU (bounded by LDS and VGPRs)
 };
 
-void launch_generate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue q, uint32_t *count0);
+// seed_hits != null: also copies each pixel's camera-ray hit (found for a one-frame queue of segment capacity
+// seed_segcap) into `hits` for every frame of the batch; q.tp may be null (rays only)
+void launch_generate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue q, uint32_t *count0,
+                     const float4 *seed_hits = nullptr, uint32_t seed_segcap = 0, float4 *hits = nullptr);
 // ints of global memory the traversal kernel needs for stack entries beyond its LDS part (per launch grid)
 size_t intersect_overflow_ints(const LaunchCfg &lc);
 bool scene_has_flat(const SceneDev &sc);

@@ -42,7 +42,7 @@ class Params(C.Structure):
                 ("max_dist", C.c_float), ("ao_length", C.c_float), ("hdri_strength", C.c_float),
                 ("accel", C.c_uint32), ("frames_in_flight", C.c_uint32), ("fused_compaction", C.c_uint32),
                 ("collect_stats", C.c_uint32), ("profile_kernels", C.c_uint32), ("batch_lanes", C.c_uint32),
-                ("reserved", C.c_uint32 * 4)]
+                ("trace_primary_per_frame", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 class Counters(C.Structure):

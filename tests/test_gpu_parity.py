@@ -88,12 +88,18 @@ def test_builtin_against_llvmpipe_goldens(size, textures):
 
 def test_config1_16spp(textures, oracle_builtin):
     """BASELINE config 1: 640x360, 16 spp, path traced, 32-bounce cap, running mean"""
-    with make_renderer(640, 360, textures) as r:
+    with make_renderer(640, 360, textures, trace_primary_per_frame=1) as r:
         r.set_mode(kl.MODE_PT)
         r.render_frames(16)
         assert r.frame == 16
         acc = r.read_accum()
         cn = r.counters()
+        # library default: the camera ray of a pixel traced once for the 16 frames of the batch, same image
+        r.update_params(trace_primary_per_frame=0)
+        r.reset(); r.reset_counters()
+        r.render_frames(16)
+        assert_bitexact(r.read_accum(), acc, "config 1 with shared camera-ray hits")
+        assert r.counters().rays == cn.rays - 15 * 640 * 360
     p = ko.default_params(width=640, height=360, mode=ko.MODE_PT, max_frames=30)
     ocn = ko.Counters()
     want = ko.render_mean(oracle_builtin, ko.default_camera(), p, 16, counters=ocn)

@@ -204,3 +204,30 @@ def test_batch_lanes_do_not_change_the_image(lanes, small_scene, textures):
     want = ko.render_mean(sc, ko.default_camera(), p, 11)
     assert_bitexact(acc, want, "running mean with %d lanes" % lanes)
     assert np.isfinite(raw).all()
+
+
+@pytest.mark.parametrize("mode", [kl.MODE_Z, kl.MODE_AO, kl.MODE_PT])
+def test_shared_camera_ray_hits_do_not_change_the_image(mode, small_scene, textures):
+    """the camera ray of a pixel is the same in every frame; tracing it once per batch or once per frame gives the
+    same bits, in every view mode, with ragged sizes and with shards"""
+    s, q, t, m = small_scene
+    w, h = 77, 41
+
+    def run(per_frame, shard=None):
+        with kl.Renderer(w, h) as r:
+            r.upload_scene(s, q, t, m)
+            r.upload_texture(kl.TEX_HDRI, textures["hdri"]); r.upload_texture(kl.TEX_ALBEDO, textures["albedo"])
+            r.update_params(max_bounces=6, max_frames=0, frames_in_flight=4, trace_primary_per_frame=per_frame, accel=kl.ACCEL_BVH)
+            r.set_mode(mode)
+            if shard:
+                r.set_shard(*shard)
+            r.render_frames(9)              # batches of 4, 4 and 1 frames
+            return r.read_accum(), r.counters().rays
+
+    a, rays_a = run(1)
+    b, rays_b = run(0)
+    assert_bitexact(b, a, "shared camera-ray hits, mode %d" % mode)
+    assert rays_b < rays_a
+    c, _ = run(0, shard=(1, 3, 5))
+    rows = [y for y in range(h) if (y // 5) % 3 == 1]
+    assert_bitexact(c, a[rows], "shared camera-ray hits on a shard")
