@@ -514,12 +514,8 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     build_bvh(s, ns, q, nq, t, nt, bvh, threads, small ? 0.0f : 0.02f, 32);
     // one array of 64-byte records: nodes, then spheres, quads, triangles in leaf order (layout: kl_types.hpp)
     auto bits = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
-#if KL_BVH4
     collapse_bvh4(bvh);
     const uint32_t n_nodes = (uint32_t)(bvh.nodes4.size() / 16);
-#else
-    const uint32_t n_nodes = bvh.stats.nodes;
-#endif
     const uint32_t base[3] = { n_nodes, n_nodes + ns, n_nodes + ns + nq };
     const size_t n_rec = std::max<size_t>((size_t)n_nodes + ns + nq + nt, 1);   // record 0 always exists
     if (n_rec >= MAX_RECORDS) return fail(c, KL_E_LIMIT, "nodes + primitives exceed 2^26 records");
@@ -529,7 +525,6 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
         uint32_t lv = (uint32_t)~child, type = (lv >> 29) & 3u, cnt = ((lv >> 26) & 7u) + 1u, start = lv & 0x3FFFFFFu;
         return make_leaf(type, base[type] + start, cnt);
     };
-#if KL_BVH4
     for (uint32_t k = 0; k < n_nodes; k++) {
         uint32_t w[16]; std::memcpy(w, &bvh.nodes4[(size_t)k * 16], sizeof w);
         for (int j = 12; j < 16; j++) w[j] = (uint32_t)patch_child((int32_t)w[j]);
@@ -537,17 +532,6 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     }
     const int32_t tree_root = bvh.root4;
     bvh.stats.nodes = n_nodes; bvh.stats.max_depth = bvh.depth4; bvh.stats.node_bytes = (uint64_t)n_nodes * 64u;
-#else
-    for (uint32_t k = 0; k < n_nodes; k++) {
-        const float *nd = &bvh.nodes[(size_t)k * 16];
-        int32_t c0, c1; std::memcpy(&c0, nd + 12, 4); std::memcpy(&c1, nd + 13, 4);
-        rec[4 * (size_t)k] = make_float4(nd[0], nd[1], nd[2], nd[3]);
-        rec[4 * (size_t)k + 1] = make_float4(nd[4], nd[5], nd[6], nd[7]);
-        rec[4 * (size_t)k + 2] = make_float4(nd[8], nd[9], nd[10], nd[11]);
-        rec[4 * (size_t)k + 3] = make_float4(bits((uint32_t)patch_child(c0)), bits((uint32_t)patch_child(c1)), 0.0f, 0.0f);
-    }
-    const int32_t tree_root = bvh.root;
-#endif
     for (uint32_t k = 0; k < ns; k++) {
         const kl_sphere &x = s[bvh.sph_order[k]];
         float4 *r = &rec[4 * ((size_t)base[PRIM_SPHERE] + k)];

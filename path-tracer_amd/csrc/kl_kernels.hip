@@ -97,16 +97,9 @@ __device__ __forceinline__ bool quad_intersect(v3 o, v3 d, v3 v0, v3 v1, v3 v2, 
 }
 // two-sided Moeller-Trumbore on (v0, e1, e2) with explicit fused multiply-adds (no reference counterpart)
 __device__ __forceinline__ bool tri_intersect(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float &t, float &bu, float &bv) {
-#ifdef KL_EXP_NOTRI
-    return false;
-#endif
     v3 p = fcross(d, e2);
     float det = fdot(e1, p);
-#ifdef KL_EXP_FASTRCP
-    float inv = __builtin_amdgcn_rcpf(det);
-#else
     float inv = 1.0f / det;
-#endif
     v3 s = o - v0;
     float u = fdot(s, p) * inv;
     if (!(u >= 0.0f && u <= 1.0f)) return false;
@@ -309,9 +302,6 @@ constexpr uint32_t ISECT_CHUNK = KL_ISECT_CHUNK;   // rays a wave takes from its
 #ifndef KL_ISECT_REFILL
 #define KL_ISECT_REFILL 48
 #endif
-#ifndef KL_ISECT_COOP
-#define KL_ISECT_COOP 1            // quad-cooperative LDS-DMA record fetch (0: every lane loads its own record)
-#endif
 #ifndef KL_ISECT_LDS_STACK
 #define KL_ISECT_LDS_STACK 10      // stack entries per lane kept in LDS; 10 + the staging area lets six workgroups share a CU
 #endif
@@ -332,15 +322,11 @@ constexpr uint32_t ISECT_REFILL = KL_ISECT_REFILL;   // refill idle lanes when f
 // consecutive lanes on consecutive banks); deeper entries (rare) spill to a per-wave slab in global memory.
 constexpr uint32_t ISECT_LDS_STACK = KL_ISECT_LDS_STACK;
 // a binary step pushes at most one entry per level, a 4-wide step at most three
-constexpr uint32_t ISECT_STACK_MAX = KL_BVH4 ? 3u * BVH_MAX_DEPTH : (uint32_t)BVH_MAX_DEPTH;
+constexpr uint32_t ISECT_STACK_MAX = 3u * BVH_MAX_DEPTH;
 constexpr uint32_t ISECT_OVF_STACK = ISECT_STACK_MAX > ISECT_LDS_STACK ? ISECT_STACK_MAX - ISECT_LDS_STACK : 1;
 constexpr uint32_t STAGE_REGION_F4 = 65;      // 64 float4 (1 KiB) of payload + 16 bytes of skew per region
 
 typedef __attribute__((address_space(3))) void lds_void_t;
-typedef float vf2 __attribute__((ext_vector_type(2)));       // pairs for the packed fp32 multiply-add
-#ifndef KL_ISECT_PK
-#define KL_ISECT_PK 0
-#endif
 typedef __attribute__((address_space(3))) int lds_int_t;      // explicit LDS pointers: stack accesses stay ds_read / ds_write
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
@@ -358,9 +344,7 @@ template <bool STATS>
 __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_intersect_bvh(SceneDev sc, FrameDev f, RayQueue q, float4 *hits, uint32_t seeded,
                                                                    const uint32_t *counts, uint32_t *heads, Counters *cn, int *overflow) {
     __shared__ int stack[ISECT_WAVES][ISECT_LDS_STACK][64];
-#if KL_ISECT_COOP
     __shared__ float4 stage[ISECT_WAVES][4][STAGE_REGION_F4];
-#endif
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: LDS bases stay scalar
     lds_int_t *st = (lds_int_t *)&stack[wave_in_block][0][lane];
@@ -433,7 +417,6 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
             const uint32_t lv = (uint32_t)~node;
             const uint32_t type = (lv >> 29) & 3u, start = lv & 0x3FFFFFFu;
             const uint32_t record = inner ? (uint32_t)node : start;
-#if KL_ISECT_COOP
             // all 64 lanes take part (a quad serves its busy members); an idle lane names record 0
             const uint32_t my_offset = active ? record << 6 : 0u;
             const uint32_t slice = (lane & 3u) << 4;
@@ -451,20 +434,7 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
             if (active && tp >= ISECT_LDS_STACK) top = ovf[(tp - ISECT_LDS_STACK) * 64u];
             const float4 *mine = &stage[wave_in_block][lane & 3u][(lane >> 2) * 4u];
             const float4 n0 = mine[0], n1 = mine[1], n2 = mine[2], n3 = mine[3];
-#endif
-#ifdef KL_EXP_EXTRA_VALU
-            {   // timing experiment only: N extra dependent VALU operations per step
-                float xx = n0.x;
-                #pragma unroll
-                for (int e = 0; e < KL_EXP_EXTRA_VALU; e++) xx = fmaf(xx, 1.0000001f, 0.5f);
-                asm volatile("" :: "v"(xx));
-            }
-#endif
             if (active) {
-#if !KL_ISECT_COOP
-                const float4 *rec = sc.rec + 4u * record;
-                const float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
-#endif
                 bool pop = false;
                 auto push = [&](int ref) {
                     if ((uint32_t)sp < ISECT_LDS_STACK) st[sp * 64] = ref;
@@ -473,7 +443,6 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                 };
                 if (inner) {
                     if (STATS) s_nodes++;
-#if KL_BVH4
                     // four child boxes on the node's 8-bit grid: plane = lo + byte * step, so along the ray
                     // t = byte * (step * 1/d) + (lo - o) * 1/d; near and far planes are picked by the sign of 1/d.
                     // An empty slot holds an inverted box and fails the test by itself.
@@ -488,22 +457,6 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                     int ref[4] = { __float_as_int(n3.x), __float_as_int(n3.y), __float_as_int(n3.z), __float_as_int(n3.w) };
                     float key[4];
                     const float inf = __builtin_huge_valf();
-#if KL_ISECT_PK
-                    // (near, far) of one axis in one packed multiply-add
-                    const vf2 Ax2 = { Ax, Ax }, Ay2 = { Ay, Ay }, Az2 = { Az, Az }, Bx2 = { Bx, Bx }, By2 = { By, By }, Bz2 = { Bz, Bz };
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const vf2 bx = { (float)((nx >> (8 * k)) & 0xFFu), (float)((fx >> (8 * k)) & 0xFFu) };
-                        const vf2 by = { (float)((ny >> (8 * k)) & 0xFFu), (float)((fy >> (8 * k)) & 0xFFu) };
-                        const vf2 bz = { (float)((nz >> (8 * k)) & 0xFFu), (float)((fz >> (8 * k)) & 0xFFu) };
-                        const vf2 tx = __builtin_elementwise_fma(bx, Ax2, Bx2);
-                        const vf2 ty = __builtin_elementwise_fma(by, Ay2, By2);
-                        const vf2 tz = __builtin_elementwise_fma(bz, Az2, Bz2);
-                        const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
-                        const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, h.t));
-                        key[k] = tn <= tf ? tn : inf;
-                    }
-#else
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const float tnx = fmaf((float)((nx >> (8 * k)) & 0xFFu), Ax, Bx), tfx = fmaf((float)((fx >> (8 * k)) & 0xFFu), Ax, Bx);
@@ -513,7 +466,6 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                         const float tf = fminf(fminf(tfx, tfy), fminf(tfz, h.t));
                         key[k] = tn <= tf ? tn : inf;
                     }
-#endif
                     // sort the four (entry distance, child) pairs, nearest first
                     auto cswap = [&](int a, int b) {
                         const bool sw = key[b] < key[a];
@@ -536,28 +488,6 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                         }
                         node = ref[0];
                     } else pop = true;
-#else
-                    float ax0 = fmaf(n0.x, id.x, nood.x), ax1 = fmaf(n0.w, id.x, nood.x);
-                    float ay0 = fmaf(n0.y, id.y, nood.y), ay1 = fmaf(n1.x, id.y, nood.y);
-                    float az0 = fmaf(n0.z, id.z, nood.z), az1 = fmaf(n1.y, id.z, nood.z);
-                    float t0n = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.0f));
-                    float t0f = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), h.t));
-                    float bx0 = fmaf(n1.z, id.x, nood.x), bx1 = fmaf(n2.y, id.x, nood.x);
-                    float by0 = fmaf(n1.w, id.y, nood.y), by1 = fmaf(n2.z, id.y, nood.y);
-                    float bz0 = fmaf(n2.x, id.z, nood.z), bz1 = fmaf(n2.w, id.z, nood.z);
-                    float t1n = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.0f));
-                    float t1f = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), h.t));
-                    bool hit0 = t0n <= t0f, hit1 = t1n <= t1f;
-                    int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                    if (hit0 && hit1) {
-                        bool swap = t1n < t0n;
-                        int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                        push(farc);
-                        node = nearc;
-                    } else if (hit0) node = c0;
-                    else if (hit1) node = c1;
-                    else pop = true;
-#endif
                 } else {
                     if (type == PRIM_TRI) { test_tri(n0, n1, n2, start, o, d, h); if (STATS) s_tri++; }
                     else if (type == PRIM_SPHERE) { test_sphere(n0, n1, start, o, d, f.eps, h); if (STATS) s_sph++; }
@@ -568,11 +498,7 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                 if (pop) {
                     if (sp > 0) {
                         sp--;
-#if KL_ISECT_COOP
                         node = top;
-#else
-                        node = (uint32_t)sp < ISECT_LDS_STACK ? st[sp * 64] : ovf[((uint32_t)sp - ISECT_LDS_STACK) * 64u];
-#endif
                     } else {
                         // the address is formed here, from the ray index, rather than carried through the loop in two registers
                         uint32_t slot = ray;
@@ -638,11 +564,7 @@ __device__ __forceinline__ v3 tex_fetch(const SceneDev &sc, int which, float u, 
     float fx = floorf(u * (float)w), fy = floorf(v * (float)hgt);
     uint32_t ix = !(fx >= 0.0f) ? 0u : (fx >= (float)w ? w - 1u : (uint32_t)fx);
     uint32_t iy = !(fy >= 0.0f) ? 0u : (fy >= (float)hgt ? hgt - 1u : (uint32_t)fy);
-#ifdef KL_EXP_NOTEX
-    uchar4 px = make_uchar4((unsigned char)ix, (unsigned char)iy, 7, 255);   // timing experiment only
-#else
     uchar4 px = sc.tex[which][(size_t)iy * w + ix];
-#endif
     const float k = 1.0f / 255.0f;
     return V((float)px.x * k, (float)px.y * k, (float)px.z * k);
 }
@@ -791,11 +713,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
                 }
                 if (!done && bounce + 1 >= f.max_bounces) { done = true; col = V(0, 0, 0); }   // RF:406
             }
-#ifdef KL_EXP_NORAW
-            if (done && col.x == 12345.0f) raw[path] = make_float4(col.x, col.y, col.z, 1.0f);   // timing experiment only
-#else
             if (done) raw[path] = make_float4(col.x, col.y, col.z, 1.0f);
-#endif
             alive = !done;
         }
         if (fused) {

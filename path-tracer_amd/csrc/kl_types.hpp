@@ -13,8 +13,7 @@ namespace kl {
 // named by its index in that array, so its address is base + (index << 6): 32-bit arithmetic, one
 // scalar base. The traversal loop fetches "the next record" with one group of loads whether the
 // lane stands on an inner node or on a primitive.
-//   node:   q0 = (lo0.x, lo0.y, lo0.z, hi0.x)   q1 = (hi0.y, hi0.z, lo1.x, lo1.y)
-//           q2 = (lo1.z, hi1.x, hi1.y, hi1.z)   q3 = (child0, child1, 0, 0) as int bits
+//   node:   four children with 8-bit boxes, see "4-wide node" below
 //   sphere: q0 = (c.xyz, r)          q1 = (id bits, material bits, 0, 0)
 //   quad:   q0 = (v0.xyz, v1.x)      q1 = (v1.yz, v2.xy)   q2 = (v2.z, v3.xyz)   q3 = (id bits, material bits, 0, 0)
 //   tri:    q0 = (v0.xyz, e1.x)      q1 = (e1.yz, e2.xy)   q2 = (e2.z, id bits, material bits, 0)
@@ -36,10 +35,7 @@ __host__ __device__ inline int make_leaf(uint32_t type, uint32_t start, uint32_t
     return ~(int)((type << 29) | ((count - 1u) << 26) | start);
 }
 constexpr uint32_t MAX_RECORDS = 1u << 26;  // nodes + primitives
-#ifndef KL_BVH4
-#define KL_BVH4 1            // 1: the traversal kernel walks the 4-wide quantised form of the tree (0: binary, full-precision boxes)
-#endif
-// 4-wide node (KL_BVH4), 16 words:
+// 4-wide node, 16 words:
 //   w0..w2 = node box lo (float)   w3..w5 = grid step of each axis (float, a power of two)
 //   w6..w8 = child lo.x / lo.y / lo.z, one byte per child (byte k = child k)   w9..w11 = child hi.x / hi.y / hi.z
 //   w12..w15 = child references (as in the binary node)
