@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -47,7 +48,7 @@ template <typename T> struct DevBuf {
 constexpr uint32_t KL_MAX_BATCH_LANES = 4;
 struct BatchLane {
     hipStream_t stream = nullptr;
-    DevBuf<float4> d_od[2], d_tp[2], d_hits, d_raw;
+    DevBuf<float4> d_od[2], d_tp[2], d_hits[2], d_raw;   // hit records ping-pong like the queues: shade reads one, writes the next bounce's flat hits into the other
     DevBuf<float2> d_d2[2];
     DevBuf<float4> p_od, p_hits;      // one-frame queue of the camera rays and their hits, shared by the frames of a batch
     DevBuf<float2> p_d2;
@@ -56,7 +57,7 @@ struct BatchLane {
     hipEvent_t done = nullptr;        // recorded after the lane's latest accumulate
     void release() {
         for (int k = 0; k < 2; k++) { d_od[k].release(); d_d2[k].release(); d_tp[k].release(); }
-        d_hits.release(); d_raw.release(); d_qctl.release(); d_overflow.release();
+        d_hits[0].release(); d_hits[1].release(); d_raw.release(); d_qctl.release(); d_overflow.release();
         p_od.release(); p_hits.release(); p_d2.release();
     }
 };
@@ -73,6 +74,7 @@ struct kl_ctx {
     uint32_t accum_mode = KL_ACCUM_MEAN;
     uint32_t frame = 0;
     bool camera_change = true;
+    bool flat_separate = false;       // KL_FLAT_SEPARATE=1: flat primitives by their own pass instead of inside generate / shade (A/B switch)
     // scene
     bool have_scene = false;
     uint32_t n_prims = 0;
@@ -133,15 +135,15 @@ uint32_t choose_slots(kl_ctx *c) {
     if (f == 0) {
         // Large batches: every launch ends in a tail of long rays during which the CUs drain, and the tail costs
         // the same whatever the launch holds, so a batch takes as many frames as memory comfortably allows
-        // (about 112 bytes of queue, hit and raw-frame storage per path; at most a quarter of the free memory
+        // (128 bytes of queue, hit and raw-frame storage per path; at most a quarter of the free memory
         // for all lanes together, and at most 128 Mi paths).
         const uint64_t npl = std::max<uint32_t>(c->npl, 1);
         uint64_t paths = 128ull << 20;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
             uint64_t held = 0;                               // what the lanes already hold counts as available
-            for (uint32_t l = 0; l < KL_MAX_BATCH_LANES; l++) held += (uint64_t)c->lanes[l].d_raw.n * 112u;
-            paths = std::min<uint64_t>(paths, ((uint64_t)free_b + held) / 4u / (112u * 2u));
+            for (uint32_t l = 0; l < KL_MAX_BATCH_LANES; l++) held += (uint64_t)c->lanes[l].d_raw.n * 128u;
+            paths = std::min<uint64_t>(paths, ((uint64_t)free_b + held) / 4u / (128u * 2u));
         }
         f = (uint32_t)std::min<uint64_t>(KL_MAX_FRAMES_IN_FLIGHT, std::max<uint64_t>(1, paths / npl));
         while (f > 1 && (uint64_t)f * npl >= (1ull << 31)) f--;
@@ -184,7 +186,7 @@ kl_status ensure_buffers(kl_ctx *c, uint32_t lanes = 1, uint32_t frames = 1) {
         for (int k = 0; k < 2; k++) {
             KL_HIP(c, L.d_od[k].alloc(qcap)); KL_HIP(c, L.d_d2[k].alloc(qcap)); KL_HIP(c, L.d_tp[k].alloc(qcap));
         }
-        KL_HIP(c, L.d_hits.alloc(qcap));
+        KL_HIP(c, L.d_hits[0].alloc(qcap)); KL_HIP(c, L.d_hits[1].alloc(qcap));
         KL_HIP(c, L.d_raw.alloc(cap));
         KL_HIP(c, L.d_qctl.alloc(2 * ((size_t)c->params.max_bounces + 3) * KL_QUEUE_SEGMENTS * CTR_STRIDE));
         KL_HIP(c, L.p_od.alloc(qcap1)); KL_HIP(c, L.p_d2.alloc(qcap1)); KL_HIP(c, L.p_hits.alloc(qcap1));
@@ -258,10 +260,12 @@ bool use_bvh(const kl_ctx *c) {
     return c->n_prims > KL_BRUTE_AUTO_LIMIT;
 }
 
-kl_status timed_intersect(kl_ctx *c, BatchLane &L, const FrameDev &f, RayQueue q, float4 *hits, uint32_t *count, uint32_t *head, uint32_t max_rays) {
+// `flat_done`: the kernel that produced the rays has already written their flat-primitive hit records
+kl_status timed_intersect(kl_ctx *c, BatchLane &L, const FrameDev &f, RayQueue q, float4 *hits, uint32_t *count, uint32_t *head, uint32_t max_rays,
+                          bool flat_done) {
     hipEvent_t a = nullptr, b = nullptr;
     const bool bvh = use_bvh(c);
-    if (bvh && scene_has_flat(c->sc))
+    if (bvh && scene_has_flat(c->sc) && !flat_done)
         launch_intersect_flat(L.stream, c->lc, c->sc, f, q, hits, count, c->d_counters.p, c->params.collect_stats != 0, max_rays);
     // the events bracket the dominant kernel only (k_intersect_bvh, or the flat loop for small scenes)
     if (c->params.profile_kernels) {
@@ -270,7 +274,7 @@ kl_status timed_intersect(kl_ctx *c, BatchLane &L, const FrameDev &f, RayQueue q
         if (a && b) KL_HIP(c, hipEventRecord(a, L.stream));
     }
     launch_intersect(L.stream, c->lc, c->sc, f, q, hits, count, head, c->d_counters.p, L.d_overflow.p, bvh,
-                     c->params.collect_stats != 0, max_rays);
+                     c->params.collect_stats != 0, max_rays, flat_done);
     if (a && b) { KL_HIP(c, hipEventRecord(b, L.stream)); c->pending.push_back({a, b, 0}); }
     return KL_OK;
 }
@@ -292,26 +296,33 @@ kl_status render_batch(kl_ctx *c, BatchLane &L, hipEvent_t after, uint32_t first
     // Every frame of the batch starts with the same camera ray per pixel: unless told otherwise, that ray is traced
     // once (a one-frame queue of its own) and generate copies its hit to the paths of all frames.
     const bool shared = nslots > 1 && c->params.trace_primary_per_frame == 0;
+    // The flat primitives (scene-spanning ones kept out of the tree) are tested by the kernel that makes a ray, generate
+    // or shade, while the ray is in registers; only the stand-alone compaction moves rays afterwards and needs the
+    // separate flat pass. Hit records ping-pong with the queues: shade reads hits[b & 1] and writes the other.
+    const bool pflat = use_bvh(c) && scene_has_flat(c->sc) && fused && !c->flat_separate;
+    float4 *hits[2] = { L.d_hits[0].p, L.d_hits[1].p };
     if (shared) {
         FrameDev f1 = f; f1.nslots = 1; f1.segcap = c->segcap1;
         uint32_t *count1 = count + (size_t)(B + 2) * S, *head1 = head + (size_t)(B + 2) * S;
         KL_HIP(c, hipMemsetAsync(count1, 0, S * sizeof(uint32_t), L.stream));
         KL_HIP(c, hipMemsetAsync(head1, 0, S * sizeof(uint32_t), L.stream));
         RayQueue q1 = { L.p_od.p, L.p_d2.p, nullptr };
-        launch_generate(L.stream, c->lc, f1, q1, count1);
-        kl_status s1 = timed_intersect(c, L, f1, q1, L.p_hits.p, count1, head1, c->npl);
+        launch_generate(L.stream, c->lc, c->sc, f1, q1, count1, nullptr, 0, L.p_hits.p, pflat);
+        kl_status s1 = timed_intersect(c, L, f1, q1, L.p_hits.p, count1, head1, c->npl, pflat);
         if (s1 != KL_OK) return s1;
-        launch_generate(L.stream, c->lc, f, q[0], count, L.p_hits.p, c->segcap1, L.d_hits.p);
+        launch_generate(L.stream, c->lc, c->sc, f, q[0], count, L.p_hits.p, c->segcap1, hits[0]);
     } else {
-        launch_generate(L.stream, c->lc, f, q[0], count);
+        launch_generate(L.stream, c->lc, c->sc, f, q[0], count, nullptr, 0, hits[0], pflat);
     }
     for (uint32_t b = 0; b < levels; b++) {
         RayQueue qi = q[b & 1u], qo = q[(b + 1u) & 1u];
+        float4 *hi = pflat ? hits[b & 1u] : hits[0];
         if (!(shared && b == 0)) {
-            kl_status s = timed_intersect(c, L, f, qi, L.d_hits.p, count + (size_t)b * S, head + (size_t)b * S, max_rays);
+            kl_status s = timed_intersect(c, L, f, qi, hi, count + (size_t)b * S, head + (size_t)b * S, max_rays, pflat);
             if (s != KL_OK) return s;
         }
-        launch_shade(L.stream, c->lc, c->sc, f, qi, L.d_hits.p, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, L.d_raw.p, b, fused, max_rays);
+        launch_shade(L.stream, c->lc, c->sc, f, qi, hi, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, L.d_raw.p, b, fused, max_rays,
+                     pflat && b + 1 < levels ? hits[(b + 1u) & 1u] : nullptr);
         if (!fused && b + 1 < levels) launch_compact(L.stream, c->lc, f, qi, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, max_rays);
     }
     if (after) KL_HIP(c, hipStreamWaitEvent(L.stream, after, 0));
@@ -378,6 +389,7 @@ kl_status kl_create(kl_ctx **out, int32_t device, uint32_t width, uint32_t heigh
 #define KL_ISECT_BLOCKS_PER_CU 6     // 4 waves x (2.5 KiB stack + 4.1 KiB fetch staging) -> six workgroups share a CU's 160 KiB LDS
 #endif
     c->lc.isect_blocks_per_cu = KL_ISECT_BLOCKS_PER_CU;
+    if (const char *e = std::getenv("KL_FLAT_SEPARATE")) c->flat_separate = e[0] == '1';
     c->width = width; c->height = height;
     kl_default_camera(&c->cam);
     kl_default_params(&c->params);

@@ -156,72 +156,6 @@ __device__ __forceinline__ bool ray_finite(v3 o, v3 d) {
     return fabsf(o.x) < inf && fabsf(o.y) < inf && fabsf(o.z) < inf && fabsf(d.x) < inf && fabsf(d.y) < inf && fabsf(d.z) < inf;
 }
 
-// ------------------------------------------------------------------ generate
-// RF:417-422 with the uv arithmetic of RF:428-429,436; one thread per (slot, pixel)
-// With `seed_hits`: every frame of a batch starts with the same camera ray per pixel (the shader adds no sub-pixel
-// jitter, RF:436 with SPP = 1), so the closest hit of that ray was found once, for a one-frame queue of segment
-// capacity `seed_segcap`, and is copied here into the hit record of each frame's path.
-__global__ __launch_bounds__(256) void k_generate(FrameDev f, RayQueue q, uint32_t *count0, const float4 *seed_hits,
-                                                  uint32_t seed_segcap, float4 *hits) {
-    const uint32_t total = f.nslots * f.npl;
-    const uint32_t groups = (total + 63u) >> 6;            // 64-path groups, dealt round-robin over the segments
-    if (blockIdx.x == 0) {
-        for (uint32_t s = threadIdx.x; s < f.nseg; s += blockDim.x) {
-            uint32_t ng = s < groups ? (groups - s + f.nseg - 1u) / f.nseg : 0u;
-            uint32_t n = ng * 64u;
-            if (ng && (groups - 1u) % f.nseg == s) n -= groups * 64u - total;   // the last group may be partial
-            count0[s * CTR_STRIDE] = n;
-        }
-    }
-    const float rx = (float)f.width, ry = (float)f.height;
-    const float m = fmaxf(rx, ry);
-    const v3 pos = ldv(f.pos), pc = ldv(f.pc), pu = ldv(f.pu), pv = ldv(f.pv);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        uint32_t slot = fastdiv(i, f.div_npl), li = i - slot * f.npl, x, y;
-        local_to_pixel(f, li, x, y);
-        float ux = (((float)x + 0.5f) - 1.0f - rx / 2.0f) / m;
-        float uy = (((float)y + 0.5f) - 1.0f - ry / 2.0f) / m;
-        if (f.mode != KL_MODE_Z) {               // RF:436 with SPP = 1
-            float psx = 1.0f / rx, psy = 1.0f / ry;
-            ux = (ux - 0.5f * psx) + (0.0f / 1.0f) * psx;
-            uy = (uy - 0.5f * psy) + (0.0f / 1.0f) * psy;
-        }
-        v3 d = normalize(pc + pu * ux + pv * uy - pos);
-        const uint32_t g = i >> 6;
-        const uint32_t dst = (g % f.nseg) * f.segcap + (g / f.nseg) * 64u + (i & 63u);
-        q.od[dst] = make_float4(pos.x, pos.y, pos.z, d.x);
-        q.d2[dst] = make_float2(d.y, d.z);
-        if (q.tp) q.tp[dst] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(i));
-        if (seed_hits) {
-            const uint32_t g0 = li >> 6;         // where generate put this pixel's ray in the one-frame queue
-            hits[dst] = seed_hits[(g0 % f.nseg) * seed_segcap + (g0 / f.nseg) * 64u + (li & 63u)];
-        }
-    }
-}
-
-// ------------------------------------------------------------------ intersect: flat loop
-// RF:294-328 for scenes of a few primitives: every lane walks the same primitive list, so the
-// geometry comes through uniform (scalar) loads and nothing but the ray and hit touch memory.
-__global__ __launch_bounds__(256) void k_intersect_brute(SceneDev sc, FrameDev f, RayQueue q, float4 *hits,
-                                                         const uint32_t *counts, Counters *cn) {
-    // block b works on segment b % nseg together with the other blocks of that residue
-    const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
-    const uint32_t count = counts[seg * CTR_STRIDE];
-    if (sub == 0 && threadIdx.x == 0 && count) atomicAdd(&cn->rays, (unsigned long long)count);
-    for (uint32_t r = sub * blockDim.x + threadIdx.x; r < count; r += nsub * blockDim.x) {
-        const uint32_t i = seg * f.segcap + r;
-        float4 od = q.od[i]; float2 d2 = q.d2[i];
-        v3 o = V(od.x, od.y, od.z), d = V(od.w, d2.x, d2.y);
-        Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
-        if (ray_finite(o, d)) {
-            test_range(sc, PRIM_SPHERE, sc.base[PRIM_SPHERE], sc.count[PRIM_SPHERE], o, d, f.eps, h);
-            test_range(sc, PRIM_QUAD, sc.base[PRIM_QUAD], sc.count[PRIM_QUAD], o, d, f.eps, h);
-            test_range(sc, PRIM_TRI, sc.base[PRIM_TRI], sc.count[PRIM_TRI], o, d, f.eps, h);
-        }
-        hits[i] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
-    }
-}
-
 // ------------------------------------------------------------------ intersect: flat primitives
 // Flat quads: the quad test of RF:218-269 with its ray-independent terms (nor, ka, kb, kg, k2, projection
 // axes) taken precomputed from upload, where they were evaluated with the same operations. All lanes walk the
@@ -260,9 +194,92 @@ __device__ __forceinline__ void flat_quads(const SceneDev &sc, v3 o, v3 d, Hit &
     }
 }
 
-// The few scene-spanning primitives kept out of the tree, tested for every ray in queue order (uniform
-// loads, no divergence). Writes the hit record that k_intersect_bvh then starts from, so the traversal
-// begins with the ray already clipped by the walls.
+// closest hit among the flat primitives (the scene-spanning ones kept out of the tree) as a hit record; the
+// traversal kernel starts from it, so it begins with the ray already clipped by the walls
+__device__ __forceinline__ float4 flat_hit(const SceneDev &sc, const FrameDev &f, v3 o, v3 d) {
+    Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
+    if (ray_finite(o, d)) {
+        test_range(sc, PRIM_SPHERE, sc.flat_start[PRIM_SPHERE], sc.flat_count[PRIM_SPHERE], o, d, f.eps, h);
+        flat_quads(sc, o, d, h);
+        test_range(sc, PRIM_TRI, sc.flat_start[PRIM_TRI], sc.flat_count[PRIM_TRI], o, d, f.eps, h);
+    }
+    return make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
+}
+
+// ------------------------------------------------------------------ generate
+// RF:417-422 with the uv arithmetic of RF:428-429,436; one thread per (slot, pixel)
+// With `seed_hits`: every frame of a batch starts with the same camera ray per pixel (the shader adds no sub-pixel
+// jitter, RF:436 with SPP = 1), so the closest hit of that ray was found once, for a one-frame queue of segment
+// capacity `seed_segcap`, and is copied here into the hit record of each frame's path.
+// With `flat` (and no seed hits): the camera ray is tested against the flat primitives here, while it is still in
+// registers, and hits[] receives the record the traversal starts from.
+__global__ __launch_bounds__(256) void k_generate(SceneDev sc, FrameDev f, RayQueue q, uint32_t *count0, const float4 *seed_hits,
+                                                  uint32_t seed_segcap, float4 *hits, uint32_t flat) {
+    const uint32_t total = f.nslots * f.npl;
+    const uint32_t groups = (total + 63u) >> 6;            // 64-path groups, dealt round-robin over the segments
+    if (blockIdx.x == 0) {
+        for (uint32_t s = threadIdx.x; s < f.nseg; s += blockDim.x) {
+            uint32_t ng = s < groups ? (groups - s + f.nseg - 1u) / f.nseg : 0u;
+            uint32_t n = ng * 64u;
+            if (ng && (groups - 1u) % f.nseg == s) n -= groups * 64u - total;   // the last group may be partial
+            count0[s * CTR_STRIDE] = n;
+        }
+    }
+    const float rx = (float)f.width, ry = (float)f.height;
+    const float m = fmaxf(rx, ry);
+    const v3 pos = ldv(f.pos), pc = ldv(f.pc), pu = ldv(f.pu), pv = ldv(f.pv);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        uint32_t slot = fastdiv(i, f.div_npl), li = i - slot * f.npl, x, y;
+        local_to_pixel(f, li, x, y);
+        float ux = (((float)x + 0.5f) - 1.0f - rx / 2.0f) / m;
+        float uy = (((float)y + 0.5f) - 1.0f - ry / 2.0f) / m;
+        if (f.mode != KL_MODE_Z) {               // RF:436 with SPP = 1
+            float psx = 1.0f / rx, psy = 1.0f / ry;
+            ux = (ux - 0.5f * psx) + (0.0f / 1.0f) * psx;
+            uy = (uy - 0.5f * psy) + (0.0f / 1.0f) * psy;
+        }
+        v3 d = normalize(pc + pu * ux + pv * uy - pos);
+        const uint32_t g = i >> 6;
+        const uint32_t dst = (g % f.nseg) * f.segcap + (g / f.nseg) * 64u + (i & 63u);
+        q.od[dst] = make_float4(pos.x, pos.y, pos.z, d.x);
+        q.d2[dst] = make_float2(d.y, d.z);
+        if (q.tp) q.tp[dst] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(i));
+        if (seed_hits) {
+            const uint32_t g0 = li >> 6;         // where generate put this pixel's ray in the one-frame queue
+            hits[dst] = seed_hits[(g0 % f.nseg) * seed_segcap + (g0 / f.nseg) * 64u + (li & 63u)];
+        } else if (flat) {
+            hits[dst] = flat_hit(sc, f, pos, d);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ intersect: flat loop
+// RF:294-328 for scenes of a few primitives: every lane walks the same primitive list, so the
+// geometry comes through uniform (scalar) loads and nothing but the ray and hit touch memory.
+__global__ __launch_bounds__(256) void k_intersect_brute(SceneDev sc, FrameDev f, RayQueue q, float4 *hits,
+                                                         const uint32_t *counts, Counters *cn) {
+    // block b works on segment b % nseg together with the other blocks of that residue
+    const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
+    const uint32_t count = counts[seg * CTR_STRIDE];
+    if (sub == 0 && threadIdx.x == 0 && count) atomicAdd(&cn->rays, (unsigned long long)count);
+    for (uint32_t r = sub * blockDim.x + threadIdx.x; r < count; r += nsub * blockDim.x) {
+        const uint32_t i = seg * f.segcap + r;
+        float4 od = q.od[i]; float2 d2 = q.d2[i];
+        v3 o = V(od.x, od.y, od.z), d = V(od.w, d2.x, d2.y);
+        Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
+        if (ray_finite(o, d)) {
+            test_range(sc, PRIM_SPHERE, sc.base[PRIM_SPHERE], sc.count[PRIM_SPHERE], o, d, f.eps, h);
+            test_range(sc, PRIM_QUAD, sc.base[PRIM_QUAD], sc.count[PRIM_QUAD], o, d, f.eps, h);
+            test_range(sc, PRIM_TRI, sc.base[PRIM_TRI], sc.count[PRIM_TRI], o, d, f.eps, h);
+        }
+        hits[i] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
+    }
+}
+
+// The flat primitives for every ray of a queue, in queue order (uniform loads, no divergence). Writes the hit
+// record that k_intersect_bvh then starts from. The render loop does not need it: generate and shade run
+// flat_hit themselves on the rays they produce; this kernel serves rays that come from elsewhere (caller
+// rays, the stand-alone compaction).
 __global__ __launch_bounds__(256) void k_intersect_flat(SceneDev sc, FrameDev f, RayQueue q, float4 *hits,
                                                         const uint32_t *counts, Counters *cn, uint32_t stats) {
     const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
@@ -275,14 +292,7 @@ __global__ __launch_bounds__(256) void k_intersect_flat(SceneDev sc, FrameDev f,
     for (uint32_t r = sub * blockDim.x + threadIdx.x; r < count; r += nsub * blockDim.x) {
         const uint32_t i = seg * f.segcap + r;
         float4 od = q.od[i]; float2 d2 = q.d2[i];
-        v3 o = V(od.x, od.y, od.z), d = V(od.w, d2.x, d2.y);
-        Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
-        if (ray_finite(o, d)) {
-            test_range(sc, PRIM_SPHERE, sc.flat_start[PRIM_SPHERE], sc.flat_count[PRIM_SPHERE], o, d, f.eps, h);
-            flat_quads(sc, o, d, h);
-            test_range(sc, PRIM_TRI, sc.flat_start[PRIM_TRI], sc.flat_count[PRIM_TRI], o, d, f.eps, h);
-        }
-        hits[i] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
+        hits[i] = flat_hit(sc, f, V(od.x, od.y, od.z), V(od.w, d2.x, d2.y));
     }
 }
 
@@ -307,7 +317,8 @@ constexpr uint32_t ISECT_CHUNK = KL_ISECT_CHUNK;   // rays a wave takes from its
 #endif
 constexpr uint32_t ISECT_REFILL = KL_ISECT_REFILL;   // refill idle lanes when fewer than this many are active
 
-// `seeded`: hits[] already holds the closest flat-primitive hit of every ray (k_intersect_flat ran).
+// `seeded`: hits[] already holds the closest flat-primitive hit of every ray (1: k_intersect_flat ran;
+// 2: the kernel that produced the rays ran the flat tests).
 //
 // Record fetch. A lane needs the 64 bytes of "its" record every step. Fetched by the lane itself that is four
 // 16-byte loads whose 64 lanes touch 64 different lines each: the L1 tag pipeline (about one line per clock
@@ -354,7 +365,14 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
     const uint32_t count = counts[seg * CTR_STRIDE];
     uint32_t *head = heads + seg * CTR_STRIDE;
     const uint32_t seg_base = seg * f.segcap;
-    if (blockIdx.x < f.nseg && threadIdx.x == 0 && count) atomicAdd(&cn->rays, (unsigned long long)count);
+    if (blockIdx.x < f.nseg && threadIdx.x == 0 && count) {
+        atomicAdd(&cn->rays, (unsigned long long)count);
+        if (STATS && seeded == 2u) {          // flat tests done by the kernel that produced the rays: tallied here
+            atomicAdd(&cn->sphere_tests, (unsigned long long)count * sc.flat_count[PRIM_SPHERE]);
+            atomicAdd(&cn->quad_tests, (unsigned long long)count * sc.flat_count[PRIM_QUAD]);
+            atomicAdd(&cn->tri_tests, (unsigned long long)count * sc.flat_count[PRIM_TRI]);
+        }
+    }
 
     uint32_t cur = 0, end = 0;               // wave-uniform: rays [cur, end) reserved by this wave
     bool exhausted = false;                  // wave-uniform: the global counter has run past count
@@ -618,11 +636,12 @@ constexpr uint32_t PATH_DEAD = 0xFFFFFFFFu;
 // ------------------------------------------------------------------ shade
 // One lane per traced ray. MODE selects the walk: RF:355-407 (path traced), RF:341-353 (AO),
 // RF:409-415 (ZDepth). A finished path writes its colour to raw[path]; a continuing one is
-// pushed to qout (fused compaction) or written back in place for k_compact.
+// pushed to qout (fused compaction) or written back in place for k_compact. With `hits_out` (fused compaction
+// only) the pushed ray also gets its flat-primitive hit record, in a hit array other than the one being read.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue qin, const float4 *hits,
                                                const uint32_t *counts_in, RayQueue qout, uint32_t *counts_out,
-                                               float4 *raw, uint32_t bounce, uint32_t fused) {
+                                               float4 *raw, uint32_t bounce, uint32_t fused, float4 *hits_out) {
     // block b works on segment b % nseg; survivors stay in their segment
     const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
     const uint32_t count = counts_in[seg * CTR_STRIDE];
@@ -722,6 +741,9 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
                 qout.od[slot_out] = make_float4(o.x, o.y, o.z, d.x);
                 qout.d2[slot_out] = make_float2(d.y, d.z);
                 qout.tp[slot_out] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(path));
+                // the flat primitives for the new ray while it is in registers: this kernel waits on memory, the
+                // flat tests are arithmetic on scalar-loaded tables, so they hide in each other
+                if (hits_out) hits_out[slot_out] = flat_hit(sc, f, o, d);
             }
         } else if (valid) {
             qin.od[i] = make_float4(o.x, o.y, o.z, d.x);
@@ -830,9 +852,10 @@ static inline uint32_t seg_grid(const FrameDev &f, uint32_t max_rays, uint32_t c
     return per_seg * f.nseg;
 }
 
-void launch_generate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue q, uint32_t *count0,
-                     const float4 *seed_hits, uint32_t seed_segcap, float4 *hits) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(f.nslots * f.npl, lc.cus * 8u)), dim3(256), 0, s, f, q, count0, seed_hits, seed_segcap, hits);
+void launch_generate(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q, uint32_t *count0,
+                     const float4 *seed_hits, uint32_t seed_segcap, float4 *hits, bool flat) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(f.nslots * f.npl, lc.cus * 8u)), dim3(256), 0, s, sc, f, q, count0, seed_hits, seed_segcap,
+                       hits, flat ? 1u : 0u);
 }
 size_t intersect_overflow_ints(const LaunchCfg &lc) {
     return (size_t)lc.cus * lc.isect_blocks_per_cu * ISECT_WAVES * ISECT_OVF_STACK * 64u;
@@ -844,24 +867,25 @@ void launch_intersect_flat(hipStream_t s, const LaunchCfg &lc, const SceneDev &s
     hipLaunchKernelGGL(k_intersect_flat, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, hits, counts, cn, stats ? 1u : 0u);
 }
 void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q, float4 *hits,
-                      const uint32_t *counts, uint32_t *heads, Counters *cn, int *overflow, bool bvh, bool stats, uint32_t max_rays) {
+                      const uint32_t *counts, uint32_t *heads, Counters *cn, int *overflow, bool bvh, bool stats, uint32_t max_rays,
+                      bool flat_by_producer) {
     if (!bvh) {
         hipLaunchKernelGGL(k_intersect_brute, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, hits, counts, cn);
         return;
     }
-    const uint32_t seeded = scene_has_flat(sc) ? 1u : 0u;
+    const uint32_t seeded = scene_has_flat(sc) ? (flat_by_producer ? 2u : 1u) : 0u;
     uint32_t blocks = seg_grid(f, max_rays, lc.cus * lc.isect_blocks_per_cu, ISECT_CHUNK * ISECT_WAVES);
     if (stats) hipLaunchKernelGGL(k_intersect_bvh<true>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, seeded, counts, heads, cn, overflow);
     else hipLaunchKernelGGL(k_intersect_bvh<false>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, seeded, counts, heads, cn, overflow);
 }
 void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin, const float4 *hits,
                   const uint32_t *count_in, RayQueue qout, uint32_t *count_out, float4 *raw, uint32_t bounce, bool fused,
-                  uint32_t max_rays) {
+                  uint32_t max_rays, float4 *hits_out) {
     dim3 g(seg_grid(f, max_rays, lc.cus * 8u, 256u)), b(256);
     uint32_t fu = fused ? 1u : 0u;
-    if (f.mode == KL_MODE_PT) hipLaunchKernelGGL(k_shade<KL_MODE_PT>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu);
-    else if (f.mode == KL_MODE_AO) hipLaunchKernelGGL(k_shade<KL_MODE_AO>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu);
-    else hipLaunchKernelGGL(k_shade<KL_MODE_Z>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu);
+    if (f.mode == KL_MODE_PT) hipLaunchKernelGGL(k_shade<KL_MODE_PT>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu, fused ? hits_out : nullptr);
+    else if (f.mode == KL_MODE_AO) hipLaunchKernelGGL(k_shade<KL_MODE_AO>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu, fused ? hits_out : nullptr);
+    else hipLaunchKernelGGL(k_shade<KL_MODE_Z>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu, fused ? hits_out : nullptr);
 }
 void launch_compact(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue qin, const uint32_t *count_in, RayQueue qout,
                     uint32_t *count_out, uint32_t max_rays) {

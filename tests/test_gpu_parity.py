@@ -109,6 +109,26 @@ def test_config1_16spp(textures, oracle_builtin):
     assert mae_clamped(acc[..., :3], ref) <= 1e-4                  # stated PT bound vs the reference shader
 
 
+def test_converged_4096spp(textures, oracle_builtin):
+    """The converged image: 4096 frames of the running mean at 160x90 (32-bounce cap) against the reference
+    shader's own 4096-frame accumulation on llvmpipe, within the stated converged-image bounds, and bit for
+    bit against the oracle's sequential mean (64 batches of 64 frames folded in frame order)."""
+    from test_oracle_golden import CONVERGED_FRAC, CONVERGED_MAE, CONVERGED_MAX_ABS, CONVERGED_REL
+    with make_renderer(160, 90, textures, max_frames=0) as r:
+        r.set_mode(kl.MODE_PT)
+        r.render_frames(4096)
+        assert r.frame == 4096
+        acc = r.read_accum()
+    ref = golden("pt_160x90_4096spp.npz")["acc"]
+    got = acc[..., :3]
+    assert mae_clamped(got, ref) <= CONVERGED_MAE
+    assert np.abs(got - ref).max() <= CONVERGED_MAX_ABS
+    assert frac_within_rel(got, ref, tol=CONVERGED_REL) >= CONVERGED_FRAC
+    p = ko.default_params(width=160, height=90, mode=ko.MODE_PT, max_frames=0)
+    want = ko.render_mean(oracle_builtin, ko.default_camera(), p, 4096)
+    assert_bitexact(acc, want, "4096-frame mean")
+
+
 @pytest.mark.parametrize("mode,name,budget", [(kl.MODE_Z, "z", 0.9999), (kl.MODE_AO, "ao", 0.99)])
 def test_config2_1080p(mode, name, budget, textures, oracle_builtin):
     """BASELINE config 2: 1920x1080, frame 0, ZDepth and AO on one GPU"""

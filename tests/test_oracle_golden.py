@@ -13,6 +13,11 @@ import pytest
 import kloracle as ko
 from conftest import frac_within_rel, golden, mae_clamped
 
+# converged-image bounds (4096 spp), shared with the GPU test of the same golden: mean absolute error of
+# clamp(x,0,1), largest absolute difference, relative tolerance and the fraction of pixels that must meet it.
+# Measured, oracle vs llvmpipe: 3.0e-6, 2.0e-3, 99.73 % (82.8 % within 1e-4, 43 % of values bit-identical).
+CONVERGED_MAE, CONVERGED_MAX_ABS, CONVERGED_REL, CONVERGED_FRAC = 1e-5, 5e-3, 1e-3, 0.99
+
 MODES = {"z": ko.MODE_Z, "ao": ko.MODE_AO, "pt": ko.MODE_PT, "ptwhite": ko.MODE_PT}
 
 
@@ -55,6 +60,18 @@ def test_config1_16spp_mean(oracle_builtin):
     assert mae_clamped(acc, ref) <= 1e-4          # measured 3e-6
     assert frac_within_rel(acc, ref) >= 0.94      # measured 0.962: any of 16 frames may flip a texel
     assert 5.7 < cn.rays / cn.paths < 6.1         # ~5.9 rays per path on this scene
+
+
+def test_converged_4096spp(oracle_builtin):
+    """The converged image: the reference's running mean over 4096 frames (SAMPLES patched to 4096) at
+    160x90, 32-bounce cap. A texel flipped by llvmpipe's atan/acos in one frame moves a pixel by at most
+    1/4096 of a texel difference, so the tolerance is far tighter than for a single frame."""
+    ref = golden("pt_160x90_4096spp.npz")["acc"]
+    p = ko.default_params(width=160, height=90, mode=ko.MODE_PT, max_frames=0)
+    acc = ko.render_mean(oracle_builtin, ko.default_camera(), p, 4096)[..., :3]
+    assert mae_clamped(acc, ref) <= CONVERGED_MAE
+    assert np.abs(acc - ref).max() <= CONVERGED_MAX_ABS
+    assert frac_within_rel(acc, ref, tol=CONVERGED_REL) >= CONVERGED_FRAC
 
 
 def test_bounce_cap_parameter(oracle_builtin):
