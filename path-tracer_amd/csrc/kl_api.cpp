@@ -80,7 +80,7 @@ struct kl_ctx {
     uint32_t n_prims = 0;
     SceneDev sc;
     kl_bvh_stats bvh_stats;
-    DevBuf<float4> d_rec, d_tri_uv, d_mats, d_flatq;
+    DevBuf<float4> d_rec, d_shrec, d_flatq;
     DevBuf<uchar4> d_tex[2];
     DevBuf<float4> d_envf;
     // wavefront state
@@ -412,7 +412,7 @@ kl_status kl_destroy(kl_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (const EventPair &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
-    c->d_rec.release(); c->d_tri_uv.release(); c->d_mats.release(); c->d_flatq.release();
+    c->d_rec.release(); c->d_shrec.release(); c->d_flatq.release();
     for (int k = 0; k < 2; k++) c->d_tex[k].release();
     c->d_envf.release();
     for (uint32_t l = 0; l < KL_MAX_BATCH_LANES; l++) {
@@ -531,7 +531,16 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     const uint32_t base[3] = { n_nodes, n_nodes + ns, n_nodes + ns + nq };
     const size_t n_rec = std::max<size_t>((size_t)n_nodes + ns + nq + nt, 1);   // record 0 always exists
     if (n_rec >= MAX_RECORDS) return fail(c, KL_E_LIMIT, "nodes + primitives exceed 2^26 records");
-    std::vector<float4> rec(n_rec * 4, make_float4(0, 0, 0, 0)), tuv((size_t)nt * 2), mats((size_t)nm * 2);
+    std::vector<float4> rec(n_rec * 4, make_float4(0, 0, 0, 0));
+    // shading records (layout: kl_types.hpp), one per primitive in record order
+    std::vector<float4> shrec(std::max<size_t>((size_t)ns + nq + nt, 1) * 4, make_float4(0, 0, 0, 0));
+    auto shade_rec = [&](size_t prim, v3 n, const kl_material &mt, float4 s2, float4 s3) {
+        float4 *r = &shrec[4 * prim];
+        r[0] = make_float4(n.x, n.y, n.z, bits((uint32_t)mt.type));
+        r[1] = make_float4(mt.color[0], mt.color[1], mt.color[2], mt.emissive);
+        r[2] = make_float4(mt.roughness, mt.ior, s2.z, s2.w);
+        r[3] = s3;
+    };
     auto patch_child = [&](int32_t child) -> int32_t {        // builder leaves count within their type
         if (child >= 0 || child == NODE_DONE) return child;
         uint32_t lv = (uint32_t)~child, type = (lv >> 29) & 3u, cnt = ((lv >> 26) & 7u) + 1u, start = lv & 0x3FFFFFFu;
@@ -549,6 +558,7 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
         float4 *r = &rec[4 * ((size_t)base[PRIM_SPHERE] + k)];
         r[0] = make_float4(x.center[0], x.center[1], x.center[2], x.radius);
         r[1] = make_float4(bits(bvh.sph_order[k]), bits(x.material), 0.0f, 0.0f);
+        shade_rec(k, V(x.center[0], x.center[1], x.center[2]), m[x.material], make_float4(0, 0, x.radius, 0.0f), make_float4(0, 0, 0, 0));
     }
     for (uint32_t k = 0; k < nq; k++) {
         const kl_quad &x = q[bvh.quad_order[k]];
@@ -557,6 +567,8 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
         r[1] = make_float4(x.v1[1], x.v1[2], x.v2[0], x.v2[1]);
         r[2] = make_float4(x.v2[2], x.v3[0], x.v3[1], x.v3[2]);
         r[3] = make_float4(bits(ns + bvh.quad_order[k]), bits(x.material), 0.0f, 0.0f);
+        v3 v1 = V(x.v1[0], x.v1[1], x.v1[2]), v2 = V(x.v2[0], x.v2[1], x.v2[2]), v3_ = V(x.v3[0], x.v3[1], x.v3[2]);
+        shade_rec((size_t)ns + k, normalize(cross(v2 - v1, v3_ - v1)), m[x.material], make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0));   // RawFrame.glsl:319
     }
     for (uint32_t k = 0; k < nt; k++) {
         const kl_tri &x = t[bvh.tri_order[k]];
@@ -567,14 +579,7 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
         r[0] = make_float4(v0.x, v0.y, v0.z, e1.x);
         r[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
         r[2] = make_float4(e2.z, bits(ns + nq + bvh.tri_order[k]), bits(x.material), 0.0f);
-        r[3] = make_float4(nor.x, nor.y, nor.z, 0.0f);
-        tuv[2 * (size_t)k] = make_float4(x.uv0[0], x.uv0[1], x.uv1[0], x.uv1[1]);
-        tuv[2 * (size_t)k + 1] = make_float4(x.uv2[0], x.uv2[1], 0.0f, 0.0f);
-    }
-    for (uint32_t k = 0; k < nm; k++) {
-        float tf; std::memcpy(&tf, &m[k].type, 4);
-        mats[2 * (size_t)k] = make_float4(tf, m[k].color[0], m[k].color[1], m[k].color[2]);
-        mats[2 * (size_t)k + 1] = make_float4(m[k].emissive, m[k].roughness, m[k].ior, 0.0f);
+        shade_rec((size_t)ns + nq + k, nor, m[x.material], make_float4(0, 0, x.uv0[0], x.uv0[1]), make_float4(x.uv1[0], x.uv1[1], x.uv2[0], x.uv2[1]));
     }
     // ray-independent terms of the quad test (RawFrame.glsl:219-244) for the flat quads, in the test's own operations
     const uint32_t nfq = bvh.flat_count[PRIM_QUAD];
@@ -601,11 +606,10 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     kl_status st;
     if ((st = upload(c, c->d_flatq, flatq.data(), flatq.size())) != KL_OK) return st;
     if ((st = upload(c, c->d_rec, rec.data(), rec.size())) != KL_OK) return st;
-    if ((st = upload(c, c->d_tri_uv, tuv.data(), tuv.size())) != KL_OK) return st;
-    if ((st = upload(c, c->d_mats, mats.data(), mats.size())) != KL_OK) return st;
+    if ((st = upload(c, c->d_shrec, shrec.data(), shrec.size())) != KL_OK) return st;
     KL_HIP(c, hipStreamSynchronize(c->stream));     // the host vectors go out of scope below
     c->sc.rec = c->d_rec.p; c->sc.root = patch_child(tree_root); c->sc.n_nodes = n_nodes;
-    c->sc.tri_uv = c->d_tri_uv.p; c->sc.mats = c->d_mats.p; c->sc.nm = nm; c->sc.flatq = c->d_flatq.p;
+    c->sc.shrec = c->d_shrec.p; c->sc.flatq = c->d_flatq.p;
     c->sc.count[PRIM_SPHERE] = ns; c->sc.count[PRIM_QUAD] = nq; c->sc.count[PRIM_TRI] = nt;
     for (int k = 0; k < 3; k++) {
         c->sc.base[k] = base[k];

@@ -545,32 +545,24 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
 }
 
 // ------------------------------------------------------------------ shading helpers
-struct Surf { v3 pos, n; bool inside; uint32_t mat; float u, v; };
+struct Surf { v3 pos, n; bool inside; float u, v; };
 
-// the fields of the shader's Hit struct (RF:142-150) that shading reads, rebuilt from (ray, t, ref)
-__device__ __forceinline__ Surf surface(const SceneDev &sc, v3 o, v3 d, float t, uint32_t ref, float hu, float hv) {
+// the fields of the shader's Hit struct (RF:142-150) that shading reads, rebuilt from (ray, t, ref) and the
+// first words of the primitive's shading record: s0.xyz = geometric normal (sphere: centre), radius (sphere only)
+__device__ __forceinline__ Surf surface(v3 o, v3 d, float t, uint32_t ref, float hu, float hv, float4 s0, float radius) {
     Surf s;
     s.pos = o + d * t;                                             // RF:304,318
-    const uint32_t type = ref_type(ref);
-    const float4 *rec = sc.rec + 4u * ref_record(ref);
-    const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
-    if (type == PRIM_SPHERE) {
-        v3 ctr = V(a.x, a.y, a.z);
+    if (ref_type(ref) == PRIM_SPHERE) {
+        v3 ctr = V(s0.x, s0.y, s0.z);
         s.n = normalize(s.pos - ctr);                              // RF:305
-        s.inside = length(o - ctr) <= a.w;                         // RF:308
+        s.inside = length(o - ctr) <= radius;                      // RF:308
         if (s.inside) s.n = s.n * -1.0f;                           // RF:309
-        s.mat = __float_as_uint(b.y); s.u = 0.0f; s.v = 0.0f;
-    } else if (type == PRIM_QUAD) {
-        v3 v1 = V(a.w, b.x, b.y), v2 = V(b.z, b.w, c.x), v3_ = V(c.y, c.z, c.w);
-        v3 nor = normalize(cross(v2 - v1, v3_ - v1));              // RF:319
-        s.n = dot(nor, d) < 0.0f ? nor : -nor;                     // faceforward, RF:320
-        s.inside = false; s.mat = __float_as_uint(e.y); s.u = hu; s.v = hv;
+        s.u = 0.0f; s.v = 0.0f;
     } else {
-        v3 nor = V(e.x, e.y, e.z);                                 // normalize(cross(e1, e2)), stored at upload
-        s.n = dot(nor, d) < 0.0f ? nor : -nor;
+        v3 nor = V(s0.x, s0.y, s0.z);                              // RF:319 for quads, stored at upload
+        s.n = dot(nor, d) < 0.0f ? nor : -nor;                     // faceforward, RF:320
         s.inside = false;
-        s.mat = __float_as_uint(c.z);
-        s.u = hu; s.v = hv;                                        // barycentrics; texture coordinates on demand
+        s.u = hu; s.v = hv;                                        // quads: uv; triangles: barycentrics
     }
     return s;
 }
@@ -633,11 +625,23 @@ __device__ __forceinline__ float fresnel(float iori, float iort, float cosi, flo
 
 constexpr uint32_t PATH_DEAD = 0xFFFFFFFFu;
 
+// one queue entry with its hit record, as shade reads them
+struct ShadeIn { float4 od; float2 d2; float4 tp; float4 hr; };
+__device__ __forceinline__ ShadeIn shade_load(const RayQueue &q, const float4 *hits, uint32_t i) {
+    ShadeIn in; in.od = q.od[i]; in.d2 = q.d2[i]; in.tp = q.tp[i]; in.hr = hits[i];
+    return in;
+}
+
 // ------------------------------------------------------------------ shade
 // One lane per traced ray. MODE selects the walk: RF:355-407 (path traced), RF:341-353 (AO),
 // RF:409-415 (ZDepth). A finished path writes its colour to raw[path]; a continuing one is
 // pushed to qout (fused compaction) or written back in place for k_compact. With `hits_out` (fused compaction
 // only) the pushed ray also gets its flat-primitive hit record, in a hit array other than the one being read.
+//
+// The kernel lives on memory latency, so the chain of dependent fetches per ray is kept short: queue entry and
+// hit record -> ONE shading record (surface and material together) -> texel. The next iteration's queue entry
+// is requested before this iteration's work starts, and the queue-tail atomic is issued as soon as the lanes
+// know whether they go on, so that its round trip runs under the flat-primitive tests.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue qin, const float4 *hits,
                                                const uint32_t *counts_in, RayQueue qout, uint32_t *counts_out,
@@ -649,28 +653,41 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
     const uint32_t seg_base = seg * f.segcap;
     const uint32_t nwaves = (nsub * blockDim.x) >> 6;
     const uint32_t wave = (sub * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = lane_id();
+    ShadeIn nxt;
+    nxt.od = make_float4(0, 0, 0, 0); nxt.d2 = make_float2(0, 0); nxt.tp = make_float4(0, 0, 0, 0); nxt.hr = make_float4(0, 0, 0, 0);
+    if (wave * 64u + lane < count) nxt = shade_load(qin, hits, seg_base + wave * 64u + lane);
     for (uint32_t base = wave * 64u; base < count; base += nwaves * 64u) {
-        const uint32_t i = seg_base + base + lane_id();
-        const bool valid = base + lane_id() < count;
+        const uint32_t i = seg_base + base + lane;
+        const bool valid = base + lane < count;
+        const ShadeIn in = nxt;
+        {   // the queue entry of the next iteration, in flight while this one is worked on
+            const uint32_t nb = base + nwaves * 64u + lane;
+            if (nb < count) nxt = shade_load(qin, hits, seg_base + nb);
+        }
         bool alive = false;
-        v3 o = V(0, 0, 0), d = V(0, 0, 0), thr = V(0, 0, 0);
-        uint32_t path = PATH_DEAD;
+        v3 o = V(in.od.x, in.od.y, in.od.z), d = V(in.od.w, in.d2.x, in.d2.y), thr = V(in.tp.x, in.tp.y, in.tp.z);
+        const uint32_t path = valid ? __float_as_uint(in.tp.w) : PATH_DEAD;
+        const float t = in.hr.x; const uint32_t ref = __float_as_uint(in.hr.y);
+        // the shading record of the primitive that was hit: the only fetch between the hit record and the texel
+        const bool hit = valid && !(t >= f.max_dist) && MODE != KL_MODE_Z;
+        float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
+        if (hit) {
+            const float4 *sr = sc.shrec + 4u * (ref_record(ref) - sc.base[PRIM_SPHERE]);
+            s0 = sr[0]; s1 = sr[1]; s2 = sr[2]; s3 = sr[3];
+        }
+        v3 col = V(0, 0, 0);
+        bool done = true;
         if (valid) {
-            float4 od = qin.od[i]; float2 d2 = qin.d2[i]; float4 tp = qin.tp[i]; float4 hr = hits[i];
-            o = V(od.x, od.y, od.z); d = V(od.w, d2.x, d2.y); thr = V(tp.x, tp.y, tp.z);
-            path = __float_as_uint(tp.w);
-            const float t = hr.x; const uint32_t ref = __float_as_uint(hr.y);
             uint32_t slot = fastdiv(path, f.div_npl), li = path - slot * f.npl, px, py;
             local_to_pixel(f, li, px, py);
             f4 r = rand4(px, py, f.first_frame + slot);
-            v3 col = V(0, 0, 0);
-            bool done = true;
             if (MODE == KL_MODE_Z) {
                 if (!(t >= f.max_dist)) { float z = 1.0f - fminf(t / 50.0f, 0.9f); col = V(z, z, z); }
             } else if (MODE == KL_MODE_AO) {
                 if (!(t >= f.max_dist)) {
                     if (bounce == 0) {
-                        Surf s = surface(sc, o, d, t, ref, hr.z, hr.w);
+                        Surf s = surface(o, d, t, ref, in.hr.z, in.hr.w, s0, s2.z);
                         d = cone_roughness(s.n, 10.0f, r);            // RF:348: theta is 10 radians
                         o = s.pos + d * f.eps;                        // RF:349
                         done = false;
@@ -683,19 +700,16 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
                 if (t >= f.max_dist) {
                     col = thr * environment(sc, f, d);                // RF:362-364
                 } else {
-                    Surf s = surface(sc, o, d, t, ref, hr.z, hr.w);
-                    float4 m0 = sc.mats[2 * s.mat], m1 = sc.mats[2 * s.mat + 1];
-                    const int mtype = __float_as_int(m0.x);
-                    const v3 mcol = V(m0.y, m0.z, m0.w);
+                    Surf s = surface(o, d, t, ref, in.hr.z, in.hr.w, s0, s2.z);
+                    const int mtype = __float_as_int(s0.w);
+                    const v3 mcol = V(s1.x, s1.y, s1.z);
                     if (mtype == KL_DIFFUSE || mtype == KL_TEXTURED) {           // RF:365-378
                         if (mtype == KL_TEXTURED) {
                             float tu = s.u, tv = s.v;
-                            if (ref_type(ref) == PRIM_TRI) {
-                                const uint32_t ti = ref_record(ref) - sc.base[PRIM_TRI];
-                                float4 s0 = sc.tri_uv[2 * ti], s1 = sc.tri_uv[2 * ti + 1];
+                            if (ref_type(ref) == PRIM_TRI) {          // texture coordinates from the corners' (s2.zw, s3.xy, s3.zw)
                                 float w = (1.0f - s.u) - s.v;
-                                tu = (s0.x * w + s0.z * s.u) + s1.x * s.v;
-                                tv = (s0.y * w + s0.w * s.u) + s1.y * s.v;
+                                tu = (s2.z * w + s3.x * s.u) + s3.z * s.v;
+                                tv = (s2.w * w + s3.y * s.u) + s3.w * s.v;
                             }
                             col = thr * tex_fetch(sc, KL_TEX_ALBEDO, tu, tv);
                         } else {
@@ -703,14 +717,14 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
                             v3 bitangent = normalize(cross(s.n, tangent));
                             v3 nl = hemisphere(r);
                             v3 local = normalize(tangent * nl.x + bitangent * nl.y + s.n * nl.z);
-                            d = normalize(mix(reflect(d, s.n), local, m1.y));
+                            d = normalize(mix(reflect(d, s.n), local, s2.x));
                             thr = thr * mcol;
                             done = false;
                         }
                     } else if (mtype == KL_GLASS) {                               // RF:379-400
                         float cosi = fabsf(dot(s.n, d));
                         float sini = sqrtf(1.0f - cosi * cosi);
-                        float iort = m1.z, iori = 1.0f;
+                        float iort = s2.y, iori = 1.0f;
                         if (s.inside) { iori = iort; iort = 1.0f; }
                         float sint = snell(sini, iori, iort);
                         float cost = sqrtf(1.0f - sint * sint);       // NaN past the critical angle: no TIR branch
@@ -724,7 +738,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
                         }
                         done = false;
                     } else if (mtype == KL_EMISSIVE) {                            // RF:401-403
-                        col = thr * mcol * m1.x;
+                        col = thr * mcol * s1.w;
                     } else {
                         done = false;                                 // unknown type: the shader's if-chain falls through
                     }
@@ -732,20 +746,28 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue
                 }
                 if (!done && bounce + 1 >= f.max_bounces) { done = true; col = V(0, 0, 0); }   // RF:406
             }
-            if (done) raw[path] = make_float4(col.x, col.y, col.z, 1.0f);
             alive = !done;
         }
         if (fused) {
-            uint32_t slot_out = seg_base + wave_reserve(count_out, alive);
-            if (alive) {
-                qout.od[slot_out] = make_float4(o.x, o.y, o.z, d.x);
-                qout.d2[slot_out] = make_float2(d.y, d.z);
-                qout.tp[slot_out] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(path));
-                // the flat primitives for the new ray while it is in registers: this kernel waits on memory, the
-                // flat tests are arithmetic on scalar-loaded tables, so they hide in each other
-                if (hits_out) hits_out[slot_out] = flat_hit(sc, f, o, d);
+            // one atomic per wave reserves the survivors' slots; issued before the colour store and the flat tests
+            const unsigned long long m = __ballot(alive);
+            uint32_t tail = 0u;
+            const uint32_t leader = m ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
+            if (m != 0ull && lane == leader) tail = atomicAdd(count_out, (uint32_t)__popcll(m));
+            if (valid && done) raw[path] = make_float4(col.x, col.y, col.z, 1.0f);
+            float4 fh = make_float4(0, 0, 0, 0);
+            if (alive && hits_out) fh = flat_hit(sc, f, o, d);
+            if (m != 0ull) {
+                const uint32_t slot_out = seg_base + (uint32_t)__shfl((int)tail, (int)leader) + mask_rank(m);
+                if (alive) {
+                    qout.od[slot_out] = make_float4(o.x, o.y, o.z, d.x);
+                    qout.d2[slot_out] = make_float2(d.y, d.z);
+                    qout.tp[slot_out] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(path));
+                    if (hits_out) hits_out[slot_out] = fh;
+                }
             }
         } else if (valid) {
+            if (done) raw[path] = make_float4(col.x, col.y, col.z, 1.0f);
             qin.od[i] = make_float4(o.x, o.y, o.z, d.x);
             qin.d2[i] = make_float2(d.y, d.z);
             qin.tp[i] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(alive ? path : PATH_DEAD));

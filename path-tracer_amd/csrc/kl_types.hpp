@@ -16,9 +16,18 @@ namespace kl {
 //   node:   four children with 8-bit boxes, see "4-wide node" below
 //   sphere: q0 = (c.xyz, r)          q1 = (id bits, material bits, 0, 0)
 //   quad:   q0 = (v0.xyz, v1.x)      q1 = (v1.yz, v2.xy)   q2 = (v2.z, v3.xyz)   q3 = (id bits, material bits, 0, 0)
-//   tri:    q0 = (v0.xyz, e1.x)      q1 = (e1.yz, e2.xy)   q2 = (e2.z, id bits, material bits, 0)
-//           q3 = (n.xyz, 0), n = normalize(cross(e1, e2)) in the shader's arithmetic
+//   tri:    q0 = (v0.xyz, e1.x)      q1 = (e1.yz, e2.xy)   q2 = (e2.z, id bits, material bits, 0)   q3 = 0
 // id = declaration-order primitive id (spheres, then quads, then triangles).
+//
+// Shading reads a second array, one 64-byte SHADING record per primitive (index = record index - base[0]),
+// holding everything the shade stage needs about the surface it hit, material included, so that one fetch
+// follows the hit record instead of a chain record -> material -> triangle uvs:
+//   s0 = (n.xyz, material type bits)   n = the geometric normal in the shader's arithmetic: quads
+//        normalize(cross(v2 - v1, v3 - v1)) (RawFrame.glsl:319), triangles normalize(cross(e1, e2));
+//        spheres: the centre instead (their normal depends on the hit point)
+//   s1 = (colour rgb, emissive strength)
+//   s2 = (roughness, ior, uv0.xy)      spheres: (roughness, ior, radius, 0)
+//   s3 = (uv1.xy, uv2.xy)              triangles only
 // child >= 0: record index of an inner node. child < 0: leaf, ~child =
 //   (type << 29) | ((count-1) << 26) | start: a run of `count` (1..8) primitives of one type whose
 //   first record is `start`.
@@ -60,9 +69,7 @@ struct SceneDev {
     // per flat quad, the ray-independent part of the quad test evaluated once at upload (5 float4 each):
     //   F0 = (v0.xyz, nor[id])  F1 = (nor.xyz, k2)  F2 = (ka.xy, kb.xy)  F3 = (kg.xy, idu | idv << 2, 0)  F4 = (id bits, 0, 0, 0)
     const float4 *flatq;
-    const float4 *tri_uv;    // 2 per triangle (by position among the triangles): (uv0.xy, uv1.xy) (uv2.xy, 0, 0)
-    const float4 *mats;      // 2 per material: (type bits, r, g, b) (emissive, roughness, ior, 0)
-    uint32_t nm;
+    const float4 *shrec;     // shading records, 4 float4 per primitive
     // textures, RGBA8, rows as uploaded
     const uchar4 *tex[2];
     uint32_t tex_w[2], tex_h[2];
