@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0, help="batches traced concurrently on separate HIP streams (0 = library default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--skip-shared", action="store_true", help="skip the second timed pass (camera-ray hits shared by a batch's frames)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events around the intersect kernel")
     args = ap.parse_args()
 
@@ -229,18 +230,20 @@ def main():
                              "frac": round(rays_rank * f_ray / isect_s / 1e12 / VALU_PEAK_TFLOPS, 4)}}
 
     # second timed pass: the library default, camera-ray hits shared by the frames of a batch
-    r.update_params(trace_primary_per_frame=0, profile_kernels=0)
-    step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    elapsed_shared = None
+    if not args.skip_shared:
+        r.update_params(trace_primary_per_frame=0, profile_kernels=0)
         step()
-    fence()
-    elapsed_shared = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed_shared], dtype=torch.float64, device="cuda")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed_shared = float(te.item())
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed_shared = time.perf_counter() - t0
+        if dist is not None:
+            te = torch.tensor([elapsed_shared], dtype=torch.float64, device="cuda")
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            elapsed_shared = float(te.item())
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
@@ -253,7 +256,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "mrays_per_s": rays_total / elapsed / 1e6, "rays_per_sample": rays_total / samples_total,
-            "value_shared_camera_rays": samples_total / elapsed_shared, "ms_per_step_shared_camera_rays": 1e3 * elapsed_shared / args.steps,
+            "value_shared_camera_rays": samples_total / elapsed_shared if elapsed_shared else None,
+            "ms_per_step_shared_camera_rays": 1e3 * elapsed_shared / args.steps if elapsed_shared else None,
             "config": {"workload": "BASELINE configs[2]: synthetic 1M-triangle textured scene, %dx%d, %d spp, %d bounces, path-traced"
                                    % (args.width, args.height, args.spp, args.bounces),
                        "triangles": int(n_tris), "bvh_nodes": int(bvh.nodes), "bvh_max_depth": int(bvh.max_depth),

@@ -112,27 +112,43 @@ __device__ __forceinline__ bool tri_intersect(v3 o, v3 d, v3 v0, v3 e1, v3 e2, f
 
 struct Hit { float t; uint32_t ref; float u, v; uint32_t id; };
 
+// declaration-order id of a primitive reference (read from its record)
+__device__ __forceinline__ uint32_t ref_id(const SceneDev &sc, uint32_t ref) {
+    const float4 *p = sc.rec + 4u * ref_record(ref);
+    const uint32_t type = ref_type(ref);
+    return type == PRIM_SPHERE ? __float_as_uint(p[1].x) : (type == PRIM_QUAD ? __float_as_uint(p[3].x) : __float_as_uint(p[2].y));
+}
+// h.id of a hit taken over from a hit record: not known, and fetched only if an exact tie asks for it
+constexpr uint32_t ID_UNKNOWN = 0xFFFFFFFEu;
+
 // acceptance rule of RF:302,316 (`t < best && t > 0.001`); on exactly equal t the lower
-// declaration-order id wins, which is what the shader's in-order loop with a strict `<` does
-__device__ __forceinline__ void accept(Hit &h, float t, uint32_t ref, uint32_t id, float u, float v) {
-    if (t > 0.001f && (t < h.t || (t == h.t && id < h.id))) { h.t = t; h.ref = ref; h.id = id; h.u = u; h.v = v; }
+// declaration-order id wins, which is what the shader's in-order loop with a strict `<` does.
+// `lazy`: h.id may be ID_UNKNOWN (h came from a hit record, which has no room for the id).
+__device__ __forceinline__ void accept(Hit &h, float t, uint32_t ref, uint32_t id, float u, float v, const SceneDev *lazy = nullptr) {
+    if (!(t > 0.001f)) return;
+    bool take = t < h.t;
+    if (t == h.t) {
+        if (lazy && h.id == ID_UNKNOWN) h.id = ref_id(*lazy, h.ref);
+        take = id < h.id;
+    }
+    if (take) { h.t = t; h.ref = ref; h.id = id; h.u = u; h.v = v; }
 }
 // primitive tests on the 64-byte records of kl_types.hpp
-__device__ __forceinline__ void test_sphere(float4 r0, float4 r1, uint32_t i, v3 o, v3 d, float eps, Hit &h) {
+__device__ __forceinline__ void test_sphere(float4 r0, float4 r1, uint32_t i, v3 o, v3 d, float eps, Hit &h, const SceneDev *lazy = nullptr) {
     float t;
-    if (sphere_intersect(o, d, r0, eps, t)) accept(h, t, make_ref(PRIM_SPHERE, i), __float_as_uint(r1.x), 0.0f, 0.0f);
+    if (sphere_intersect(o, d, r0, eps, t)) accept(h, t, make_ref(PRIM_SPHERE, i), __float_as_uint(r1.x), 0.0f, 0.0f, lazy);
 }
-__device__ __forceinline__ void test_quad(float4 a, float4 b, float4 c, float4 e, uint32_t i, v3 o, v3 d, Hit &h) {
+__device__ __forceinline__ void test_quad(float4 a, float4 b, float4 c, float4 e, uint32_t i, v3 o, v3 d, Hit &h, const SceneDev *lazy = nullptr) {
     // the plane distance is the first thing RF:225 computes; a candidate that cannot pass the
     // acceptance test of RF:316 is dropped before the inverse-bilinear solve (same outcome)
     float t, u, v;
     if (quad_intersect(o, d, V(a.x, a.y, a.z), V(a.w, b.x, b.y), V(b.z, b.w, c.x), V(c.y, c.z, c.w), h.t, t, u, v))
-        accept(h, t, make_ref(PRIM_QUAD, i), __float_as_uint(e.x), u, v);
+        accept(h, t, make_ref(PRIM_QUAD, i), __float_as_uint(e.x), u, v, lazy);
 }
-__device__ __forceinline__ void test_tri(float4 a, float4 b, float4 c, uint32_t i, v3 o, v3 d, Hit &h) {
+__device__ __forceinline__ void test_tri(float4 a, float4 b, float4 c, uint32_t i, v3 o, v3 d, Hit &h, const SceneDev *lazy = nullptr) {
     float t, u, v;
     if (tri_intersect(o, d, V(a.x, a.y, a.z), V(a.w, b.x, b.y), V(b.z, b.w, c.x), t, u, v))
-        accept(h, t, make_ref(PRIM_TRI, i), __float_as_uint(c.y), u, v);
+        accept(h, t, make_ref(PRIM_TRI, i), __float_as_uint(c.y), u, v, lazy);
 }
 // A 16-byte load from an address that is the same in every lane, through the constant address space: the
 // compiler then uses the scalar cache and scalar registers instead of 64 identical vector loads. Only for data
@@ -296,13 +312,6 @@ __global__ __launch_bounds__(256) void k_intersect_flat(SceneDev sc, FrameDev f,
     }
 }
 
-// declaration-order id of a primitive reference (read from its record)
-__device__ __forceinline__ uint32_t ref_id(const SceneDev &sc, uint32_t ref) {
-    const float4 *p = sc.rec + 4u * ref_record(ref);
-    const uint32_t type = ref_type(ref);
-    return type == PRIM_SPHERE ? __float_as_uint(p[1].x) : (type == PRIM_QUAD ? __float_as_uint(p[3].x) : __float_as_uint(p[2].y));
-}
-
 // ------------------------------------------------------------------ intersect: BVH
 constexpr uint32_t ISECT_WAVES = 4;          // waves per workgroup
 #ifndef KL_ISECT_CHUNK
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                 if (seeded) {
                     float4 hr = hits[ray];
                     h.t = hr.x; h.ref = __float_as_uint(hr.y); h.u = hr.z; h.v = hr.w;
-                    if (h.ref != REF_MISS) h.id = ref_id(sc, h.ref);    // needed only to break exact ties
+                    if (h.ref != REF_MISS) h.id = ID_UNKNOWN;           // fetched only if an exact tie asks for it
                 }
                 // slab reciprocals; a zero component is nudged so 0 * inf never appears
                 float sx = fabsf(d.x) > 1e-20f ? d.x : copysignf(1e-20f, d.x);
@@ -507,9 +516,9 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                         node = ref[0];
                     } else pop = true;
                 } else {
-                    if (type == PRIM_TRI) { test_tri(n0, n1, n2, start, o, d, h); if (STATS) s_tri++; }
-                    else if (type == PRIM_SPHERE) { test_sphere(n0, n1, start, o, d, f.eps, h); if (STATS) s_sph++; }
-                    else { test_quad(n0, n1, n2, n3, start, o, d, h); if (STATS) s_quad++; }
+                    if (type == PRIM_TRI) { test_tri(n0, n1, n2, start, o, d, h, &sc); if (STATS) s_tri++; }
+                    else if (type == PRIM_SPHERE) { test_sphere(n0, n1, start, o, d, f.eps, h, &sc); if (STATS) s_sph++; }
+                    else { test_quad(n0, n1, n2, n3, start, o, d, h, &sc); if (STATS) s_quad++; }
                     if ((lv >> 26) & 7u) node = ~(int)(lv + 1u - (1u << 26));   // next primitive of this leaf
                     else pop = true;
                 }

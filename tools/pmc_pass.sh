@@ -6,5 +6,5 @@ set -e
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -o $tag -- \
-  python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-profile > gpurun_out/pmc_$tag.log 2>&1
+  python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --skip-shared --no-profile > gpurun_out/pmc_$tag.log 2>&1
 echo "pmc pass $tag exit $?"
