@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0, help="batches traced concurrently on separate HIP streams (0 = library default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--builder", choices=("host", "gpu"), default="host",
+                    help="BVH builder: host = binned SAH on the host cores (headline), gpu = Morton-ordered tree built on the GPU")
     ap.add_argument("--skip-shared", action="store_true", help="skip the second timed pass (camera-ray hits shared by a batch's frames)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events around the intersect kernel")
     args = ap.parse_args()
@@ -123,6 +125,7 @@ def main():
     scene = kl.synth_scene(blobs=args.blobs, tris_per_blob=args.tris_per_blob, seed=1)
     n_tris = len(scene[2])
     r = kl.Renderer(args.width, args.height, device=device)
+    r.update_params(bvh_builder=kl.BUILD_GPU_LBVH if args.builder == "gpu" else kl.BUILD_HOST_SAH)
     r.upload_scene(*scene)
     r.upload_texture(kl.TEX_HDRI, bg)
     r.upload_texture(kl.TEX_ALBEDO, tx)
@@ -261,7 +264,8 @@ def main():
             "config": {"workload": "BASELINE configs[2]: synthetic 1M-triangle textured scene, %dx%d, %d spp, %d bounces, path-traced"
                                    % (args.width, args.height, args.spp, args.bounces),
                        "triangles": int(n_tris), "bvh_nodes": int(bvh.nodes), "bvh_max_depth": int(bvh.max_depth),
-                       "bvh_build_s": round(bvh.build_seconds, 3), "frames_in_flight": int(r.get_params().frames_in_flight),
+                       "bvh_build_s": round(bvh.build_seconds, 4),
+                       "bvh_builder": "GPU LBVH" if bvh.builder == kl.BUILD_GPU_LBVH else "host binned SAH", "frames_in_flight": int(r.get_params().frames_in_flight),
                        "textures": tex_note,
                        "partition": "single GPU, running mean" if world == 1 else
                                     "sample ranges: %d frames per rank, %s all-reduce(sum) per step" % (args.spp, "RCCL" if backend == "nccl" else backend)},

@@ -53,6 +53,11 @@ enum { KL_TONEMAP_CLAMP = 0, KL_TONEMAP_ACES = 1 };
 enum { KL_ACCUM_MEAN = 0, KL_ACCUM_SUM = 1 };
 /* intersection back end: brute force in declaration order (what RawFrame.glsl:294-328 does) or the SAH BVH */
 enum { KL_ACCEL_AUTO = 0, KL_ACCEL_BRUTE = 1, KL_ACCEL_BVH = 2 };
+/* who builds the tree at kl_upload_scene (no reference counterpart: the reference has no acceleration structure):
+ * HOST_SAH = binned surface-area heuristic on the host cores (the better tree, 0.1-0.2 s per million primitives);
+ * GPU_LBVH = Morton-ordered radix tree built, refitted and collapsed on the GPU (milliseconds; rays cost more in it).
+ * Both give the same images: the closest hit does not depend on the tree. */
+enum { KL_BUILD_HOST_SAH = 0, KL_BUILD_GPU_LBVH = 1 };
 #define KL_CONTINUE 0xFFFFFFFFu
 
 /* the camera uniforms iCameraPos/Front/Up/FocalLength/SensorWidth,
@@ -96,7 +101,9 @@ typedef struct kl_params {
     uint32_t trace_primary_per_frame; /* 0: the camera ray of a pixel, which is the same in every frame (RawFrame.glsl:436 adds no
                                   jitter at SPP = 1), is traced once per batch and its hit shared by the batch's frames;
                                   1: traced again for every frame, as the shader does. The image is the same either way. */
-    uint32_t reserved[3];
+    uint32_t bvh_builder;      /* KL_BUILD_*, read by the next kl_upload_scene / kl_load_mesh; a GPU build whose tree turns out
+                                  deeper than the traversal stack allows is redone on the host (kl_bvh_stats.builder says which ran) */
+    uint32_t reserved[2];
 } kl_params;
 
 typedef struct kl_counters {
@@ -122,7 +129,7 @@ typedef struct kl_bvh_stats {
     double build_seconds;
     uint64_t node_bytes, prim_bytes;
     uint32_t flat_spheres, flat_quads, flat_tris; /* scene-spanning primitives kept out of the tree and tested for every ray */
-    uint32_t reserved;
+    uint32_t builder;          /* KL_BUILD_* that produced the tree in use */
 } kl_bvh_stats;
 
 /* parameters of the seed-deterministic synthetic benchmark scene */

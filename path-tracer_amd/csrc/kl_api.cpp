@@ -15,6 +15,7 @@
 #include "Math/kl_render.h"
 #include "kl_bvh.hpp"
 #include "kl_kernels.hpp"
+#include "kl_lbvh.hpp"
 #include "kl_math.hpp"
 #include "kl_scene.hpp"
 #include "kl_types.hpp"
@@ -463,6 +464,7 @@ kl_status kl_set_params(kl_ctx *c, const kl_params *p) {
     if (p->max_bounces == 0 || p->max_bounces > KL_MAX_BOUNCES) return fail(c, KL_E_LIMIT, "max_bounces must be 1..4096");
     if (p->frames_in_flight > KL_MAX_FRAMES_IN_FLIGHT) return fail(c, KL_E_LIMIT, "frames_in_flight must be <= 64");
     if (p->accel > KL_ACCEL_BVH) return fail(c, KL_E_INVALID, "bad accel");
+    if (p->bvh_builder > KL_BUILD_GPU_LBVH) return fail(c, KL_E_INVALID, "bad bvh_builder");
     if (p->batch_lanes > KL_MAX_BATCH_LANES) return fail(c, KL_E_LIMIT, "batch_lanes must be <= 4");
     if (!(p->max_dist > 0.0f) || !(p->eps >= 0.0f)) return fail(c, KL_E_INVALID, "bad eps/max_dist");
     KL_HIP(c, hipStreamSynchronize(c->stream));
@@ -523,10 +525,19 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     // scenes small enough for the flat loop keep everything in one list; otherwise primitives whose box is
     // >= 2 % of the scene's (at most 32 of them: walls, floors, sky domes) are tested outside the tree
     const bool small = ns + nq + nt <= KL_BRUTE_AUTO_LIMIT;
-    build_bvh(s, ns, q, nq, t, nt, bvh, threads, small ? 0.0f : 0.02f, 32);
+    uint32_t builder = KL_BUILD_HOST_SAH;
+    if (c->params.bvh_builder == KL_BUILD_GPU_LBVH && !small) {
+        std::string why;
+        const LbvhResult r = build_bvh_gpu(c->stream, s, ns, q, nq, t, nt, bvh, 0.02f, 32, why);
+        if (r == LBVH_HIP_ERROR) return fail(c, KL_E_DEVICE, "GPU BVH build: " + why);
+        if (r == LBVH_OK) builder = KL_BUILD_GPU_LBVH;      // LBVH_TOO_DEEP: the host builder below
+    }
+    if (builder == KL_BUILD_HOST_SAH) {
+        build_bvh(s, ns, q, nq, t, nt, bvh, threads, small ? 0.0f : 0.02f, 32);
+        collapse_bvh4(bvh);
+    }
     // one array of 64-byte records: nodes, then spheres, quads, triangles in leaf order (layout: kl_types.hpp)
     auto bits = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
-    collapse_bvh4(bvh);
     const uint32_t n_nodes = (uint32_t)(bvh.nodes4.size() / 16);
     const uint32_t base[3] = { n_nodes, n_nodes + ns, n_nodes + ns + nq };
     const size_t n_rec = std::max<size_t>((size_t)n_nodes + ns + nq + nt, 1);   // record 0 always exists
@@ -553,6 +564,7 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     }
     const int32_t tree_root = bvh.root4;
     bvh.stats.nodes = n_nodes; bvh.stats.max_depth = bvh.depth4; bvh.stats.node_bytes = (uint64_t)n_nodes * 64u;
+    bvh.stats.builder = builder;
     for (uint32_t k = 0; k < ns; k++) {
         const kl_sphere &x = s[bvh.sph_order[k]];
         float4 *r = &rec[4 * ((size_t)base[PRIM_SPHERE] + k)];
@@ -619,7 +631,7 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     c->bvh_stats = bvh.stats;
     c->bvh_stats.prim_bytes = ((uint64_t)ns + nq + nt) * 64;
     c->bvh_stats.flat_spheres = bvh.flat_count[PRIM_SPHERE]; c->bvh_stats.flat_quads = bvh.flat_count[PRIM_QUAD];
-    c->bvh_stats.flat_tris = bvh.flat_count[PRIM_TRI]; c->bvh_stats.reserved = 0;
+    c->bvh_stats.flat_tris = bvh.flat_count[PRIM_TRI];
     c->have_scene = true;
     return kl_reset(c);
 }

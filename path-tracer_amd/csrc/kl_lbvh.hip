@@ -1,0 +1,416 @@
+// GPU-side BVH builder: see kl_lbvh.hpp.
+//
+//   bounds     : padded box and area of every primitive, scene box (wave reduction + ordered-int atomics)
+//   keys       : 63-bit Morton code of the box centre; candidates for the flat list
+//   sort       : hipCUB radix sort of (code, primitive); flat primitives carry the largest key and end up last
+//   orders     : per-type leaf orders (exclusive scans of the type flags over the sorted sequence)
+//   hierarchy  : binary radix tree over the sorted codes (Karras 2012), ties broken by position
+//   depth      : depth of every inner node (walk to the root; read-only data)
+//   refit      : boxes of the inner nodes, ONE LAUNCH PER DEPTH LEVEL from the deepest up: a node reads boxes
+//                that an earlier launch wrote, so no hand-off between workgroups happens inside a launch
+//   collapse   : 4-wide nodes with 8-bit child boxes, one launch per 4-wide level from the root down; a node
+//                opens its inner child with the largest box until it has four children (as the host collapse)
+#include "kl_lbvh.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <vector>
+
+#include <hipcub/hipcub.hpp>
+
+#include "kl_types.hpp"
+
+namespace kl {
+namespace {
+
+constexpr uint32_t FLAT_CAP = 1024;          // flat candidates the device list holds
+constexpr uint32_t WALK_CAP = 4096;          // bound of every parent walk (a tree is never this deep)
+struct FlatCand { uint32_t prim; float area; };
+
+// float <-> unsigned with the same order (for atomicMin / atomicMax on floats of either sign)
+__host__ __device__ inline uint32_t f2ord(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(uint32_t u) {
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    float f; memcpy(&f, &u, 4);
+    return f;
+}
+
+__device__ __forceinline__ void grow(float lo[3], float hi[3], const float p[3]) {
+    for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], p[k]); hi[k] = fmaxf(hi[k], p[k]); }
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_bounds(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
+                                                     float4 *blo, float4 *bhi, uint32_t *scene) {
+    const uint32_t n = ns + nq + nt;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const float inf = __builtin_huge_valf();
+    float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+    if (g < n) {
+        if (g < ns) {
+            for (int k = 0; k < 3; k++) { lo[k] = s[g].center[k] - s[g].radius; hi[k] = s[g].center[k] + s[g].radius; }
+        } else if (g < ns + nq) {
+            const kl_quad &x = q[g - ns];
+            grow(lo, hi, x.v0); grow(lo, hi, x.v1); grow(lo, hi, x.v2); grow(lo, hi, x.v3);
+        } else {
+            const kl_tri &x = t[g - ns - nq];
+            grow(lo, hi, x.v0); grow(lo, hi, x.v1); grow(lo, hi, x.v2);
+        }
+        // widened by a few ulps, like the host builder's leaves: rounding in the slab test must not cull a
+        // primitive that exact arithmetic would reach
+        for (int k = 0; k < 3; k++) {
+            const float m = fmaxf(fabsf(lo[k]), fabsf(hi[k]));
+            const float pad = 1e-6f + 4e-6f * m;
+            lo[k] -= pad; hi[k] += pad;
+        }
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        const float area = (dx < 0 || dy < 0 || dz < 0) ? 0.0f : 2.0f * (dx * dy + dy * dz + dz * dx);
+        blo[g] = make_float4(lo[0], lo[1], lo[2], area);
+        bhi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        for (int k = 0; k < 3; k++) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    if ((threadIdx.x & 63u) == 0u)
+        for (int k = 0; k < 3; k++) {
+            if (lo[k] < inf) atomicMin(&scene[k], f2ord(lo[k]));
+            if (hi[k] > -inf) atomicMax(&scene[3 + k], f2ord(hi[k]));
+        }
+}
+
+// 21 bits -> every third bit of 63
+__device__ __forceinline__ unsigned long long spread3(uint32_t v) {
+    unsigned long long x = v & 0x1FFFFFull;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_keys(const float4 *blo, const float4 *bhi, uint32_t n, const uint32_t *scene, float flat_fraction,
+                                                   FlatCand *cand, uint32_t *ncand, unsigned long long *keys, uint32_t *vals) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    float slo[3], ext[3];
+    for (int k = 0; k < 3; k++) { slo[k] = ord2f(scene[k]); ext[k] = ord2f(scene[3 + k]) - slo[k]; }
+    const float sarea = 2.0f * (ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0]);
+    const float4 lo = blo[g], hi = bhi[g];
+    if (flat_fraction > 0.0f && lo.w >= flat_fraction * sarea) {
+        const uint32_t idx = atomicAdd(ncand, 1u);
+        if (idx < FLAT_CAP) { cand[idx].prim = g; cand[idx].area = lo.w; }
+    }
+    const float c[3] = { 0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z) };
+    uint32_t ic[3];
+    for (int k = 0; k < 3; k++) {
+        float u = ext[k] > 0.0f ? (c[k] - slo[k]) / ext[k] : 0.0f;
+        u = !(u >= 0.0f) ? 0.0f : (u > 1.0f ? 1.0f : u);
+        const uint32_t i = (uint32_t)(u * 2097152.0f);
+        ic[k] = i > 2097151u ? 2097151u : i;
+    }
+    keys[g] = (spread3(ic[0]) << 2) | (spread3(ic[1]) << 1) | spread3(ic[2]);
+    vals[g] = g;
+}
+// flat primitives sort behind every Morton code (which has 63 bits)
+__global__ void k_lbvh_mark_flat(const uint32_t *flat, uint32_t nflat, unsigned long long *keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nflat) keys[flat[i]] = ~0ull;
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_typeflags(const uint32_t *vals, uint32_t n, uint32_t ns, uint32_t nq, uint32_t *f0, uint32_t *f1, uint32_t *f2) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t g = vals[p];
+    f0[p] = g < ns ? 1u : 0u;
+    f1[p] = (g >= ns && g < ns + nq) ? 1u : 0u;
+    f2[p] = g >= ns + nq ? 1u : 0u;
+}
+// position p of the sorted sequence holds primitive vals[p]; its rank among the primitives of its type is its place in
+// that type's leaf order, and a one-primitive leaf names it
+__global__ __launch_bounds__(256) void k_lbvh_orders(const uint32_t *vals, uint32_t n, uint32_t ns, uint32_t nq, const uint32_t *r0, const uint32_t *r1,
+                                                     const uint32_t *r2, uint32_t *ord_s, uint32_t *ord_q, uint32_t *ord_t, int *leafref) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t g = vals[p];
+    if (g < ns) { ord_s[r0[p]] = g; leafref[p] = make_leaf(PRIM_SPHERE, r0[p], 1u); }
+    else if (g < ns + nq) { ord_q[r1[p]] = g - ns; leafref[p] = make_leaf(PRIM_QUAD, r1[p], 1u); }
+    else { ord_t[r2[p]] = g - ns - nq; leafref[p] = make_leaf(PRIM_TRI, r2[p], 1u); }
+}
+
+// length of the common prefix of the codes at sorted positions i and j, position bits appended so that equal
+// codes still differ; -1 outside the sequence
+__device__ __forceinline__ int delta(const unsigned long long *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz(i ^ j);
+    return __clzll((long long)(a ^ b));
+}
+// inner node i of the binary radix tree over n sorted leaves. Children: >= 0 inner node, < 0 leaf at position ~c.
+__global__ __launch_bounds__(256) void k_lbvh_hierarchy(const unsigned long long *keys, int n, int *left, int *right, int *parent_int, int *parent_leaf) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n - 1) return;
+    const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (lmax < (1 << 30) && delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    if (lo == gamma) { left[i] = ~gamma; parent_leaf[gamma] = i; } else { left[i] = gamma; parent_int[gamma] = i; }
+    if (hi == gamma + 1) { right[i] = ~(gamma + 1); parent_leaf[gamma + 1] = i; } else { right[i] = gamma + 1; parent_int[gamma + 1] = i; }
+    if (i == 0) parent_int[0] = -1;
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_depth(const int *parent_int, uint32_t n_int, uint32_t *depth, uint32_t *maxdepth) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t d = 0;
+    if (i < n_int) {
+        int p = parent_int[i];
+        while (p >= 0 && d < WALK_CAP) { d++; p = parent_int[p]; }
+        depth[i] = d;
+    }
+    for (int off = 32; off > 0; off >>= 1) d = max(d, (uint32_t)__shfl_xor((int)d, off));
+    if ((threadIdx.x & 63u) == 0u) atomicMax(maxdepth, d);
+}
+
+struct CBox { float lo[3], hi[3]; };
+__device__ __forceinline__ CBox child_box(int c, const uint32_t *vals, const float4 *blo, const float4 *bhi, const float4 *ilo, const float4 *ihi) {
+    float4 a, b;
+    if (c < 0) { const uint32_t g = vals[~c]; a = blo[g]; b = bhi[g]; } else { a = ilo[c]; b = ihi[c]; }
+    CBox x; x.lo[0] = a.x; x.lo[1] = a.y; x.lo[2] = a.z; x.hi[0] = b.x; x.hi[1] = b.y; x.hi[2] = b.z;
+    return x;
+}
+__device__ __forceinline__ float box_area(const CBox &b) {
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return (dx < 0 || dy < 0 || dz < 0) ? 0.0f : 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+// boxes of the inner nodes of one depth level; their children's boxes were written by earlier launches
+__global__ __launch_bounds__(256) void k_lbvh_refit(uint32_t level, const uint32_t *depth, uint32_t n_int, const int *left, const int *right,
+                                                    const uint32_t *vals, const float4 *blo, const float4 *bhi, float4 *ilo, float4 *ihi) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_int || depth[i] != level) return;
+    const CBox a = child_box(left[i], vals, blo, bhi, ilo, ihi), b = child_box(right[i], vals, blo, bhi, ilo, ihi);
+    ilo[i] = make_float4(fminf(a.lo[0], b.lo[0]), fminf(a.lo[1], b.lo[1]), fminf(a.lo[2], b.lo[2]), 0.0f);
+    ihi[i] = make_float4(fmaxf(a.hi[0], b.hi[0]), fmaxf(a.hi[1], b.hi[1]), fmaxf(a.hi[2], b.hi[2]), 0.0f);
+}
+
+// 4-wide nodes [begin, end): node idx is built from binary node src[idx]. Its inner children get consecutive
+// 4-wide indices from `alloc` and are built by the next launch.
+__global__ __launch_bounds__(256) void k_lbvh_collapse(uint32_t begin, uint32_t end, int *src, uint32_t *alloc, const int *left, const int *right,
+                                                       const int *leafref, const uint32_t *vals, const float4 *blo, const float4 *bhi,
+                                                       const float4 *ilo, const float4 *ihi, uint32_t *nodes4) {
+    const uint32_t idx = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= end) return;
+    const int b2 = src[idx];
+    CBox box[4]; int ref[4]; int nch = 2;
+    ref[0] = left[b2]; ref[1] = right[b2];
+    box[0] = child_box(ref[0], vals, blo, bhi, ilo, ihi); box[1] = child_box(ref[1], vals, blo, bhi, ilo, ihi);
+    while (nch < 4) {                      // open the inner child with the largest box
+        int best = -1; float best_area = -1.0f;
+        for (int k = 0; k < nch; k++) {
+            const float a = box_area(box[k]);
+            if (ref[k] >= 0 && a > best_area) { best = k; best_area = a; }
+        }
+        if (best < 0) break;
+        const int open = ref[best];
+        ref[best] = left[open]; box[best] = child_box(ref[best], vals, blo, bhi, ilo, ihi);
+        ref[nch] = right[open]; box[nch] = child_box(ref[nch], vals, blo, bhi, ilo, ihi);
+        nch++;
+    }
+    float nlo[3], nhi[3];
+    for (int a = 0; a < 3; a++) {
+        nlo[a] = box[0].lo[a]; nhi[a] = box[0].hi[a];
+        for (int k = 1; k < nch; k++) { nlo[a] = fminf(nlo[a], box[k].lo[a]); nhi[a] = fmaxf(nhi[a], box[k].hi[a]); }
+    }
+    uint32_t w[16];
+    for (int k = 0; k < 16; k++) w[k] = 0u;
+    double scale[3];
+    for (int a = 0; a < 3; a++) {
+        w[a] = __float_as_uint(nlo[a]);
+        const double ext = (double)nhi[a] - (double)nlo[a];
+        int e = ext > 0.0 ? (int)ceil(log2(ext / 255.0)) : -100;
+        if (e < -100) e = -100;
+        while (ldexp(255.0, e) < ext) e++;               // guard the rounding of log2
+        scale[a] = ldexp(1.0, e);
+        w[3 + a] = __float_as_uint((float)scale[a]);     // a power of two: exact
+    }
+    for (int k = 0; k < 4; k++) {
+        uint32_t qlo[3] = { 255u, 255u, 255u }, qhi[3] = { 0u, 0u, 0u };   // empty slot: inverted box, never entered
+        if (k < nch)
+            for (int a = 0; a < 3; a++) {
+                const double l = floor(((double)box[k].lo[a] - (double)nlo[a]) / scale[a]);
+                const double h = ceil(((double)box[k].hi[a] - (double)nlo[a]) / scale[a]);
+                qlo[a] = (uint32_t)fmin(255.0, fmax(0.0, l));
+                qhi[a] = (uint32_t)fmin(255.0, fmax(0.0, h));
+            }
+        for (int a = 0; a < 3; a++) { w[6 + a] |= qlo[a] << (8 * k); w[9 + a] |= qhi[a] << (8 * k); }
+    }
+    uint32_t n_inner = 0;
+    for (int k = 0; k < nch; k++) n_inner += ref[k] >= 0 ? 1u : 0u;
+    uint32_t next = n_inner ? atomicAdd(alloc, n_inner) : 0u;
+    for (int k = 0; k < nch; k++) {
+        if (ref[k] >= 0) { src[next] = ref[k]; w[12 + k] = next++; }
+        else w[12 + k] = (uint32_t)leafref[~ref[k]];
+    }
+    for (int k = nch; k < 4; k++) w[12 + k] = w[12];     // an empty slot repeats child 0: always a valid reference
+    uint4 *dst = (uint4 *)(nodes4 + (size_t)idx * 16);
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]); dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    dst[2] = make_uint4(w[8], w[9], w[10], w[11]); dst[3] = make_uint4(w[12], w[13], w[14], w[15]);
+}
+
+struct Buf {
+    void *p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+inline uint32_t blocks_for(uint32_t n) { return n ? (n + 255u) / 256u : 1u; }
+
+}  // namespace
+
+LbvhResult build_bvh_gpu(hipStream_t stream, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq,
+                   const kl_tri *t, uint32_t nt, HostBVH &out, float flat_fraction, uint32_t max_flat, std::string &err) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t n = ns + nq + nt;
+    identity_order(0, 0, 0, out);
+    out.nodes4.clear(); out.root4 = NODE_DONE; out.depth4 = 0;
+    out.stats.spheres = ns; out.stats.quads = nq; out.stats.tris = nt;
+    if (n == 0) return LBVH_OK;
+    hipError_t e = hipSuccess;
+#define LB(call) do { e = (call); if (e != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e); return LBVH_HIP_ERROR; } } while (0)
+    Buf d_s, d_q, d_t, d_blo, d_bhi, d_scene, d_cand, d_ncand, d_keys[2], d_vals[2], d_tmp, d_flat;
+    LB(d_s.alloc((size_t)ns * sizeof(kl_sphere))); LB(d_q.alloc((size_t)nq * sizeof(kl_quad))); LB(d_t.alloc((size_t)nt * sizeof(kl_tri)));
+    if (ns) LB(hipMemcpyAsync(d_s.p, s, (size_t)ns * sizeof(kl_sphere), hipMemcpyHostToDevice, stream));
+    if (nq) LB(hipMemcpyAsync(d_q.p, q, (size_t)nq * sizeof(kl_quad), hipMemcpyHostToDevice, stream));
+    if (nt) LB(hipMemcpyAsync(d_t.p, t, (size_t)nt * sizeof(kl_tri), hipMemcpyHostToDevice, stream));
+    LB(d_blo.alloc((size_t)n * 16)); LB(d_bhi.alloc((size_t)n * 16));
+    LB(d_scene.alloc(6 * 4)); LB(d_cand.alloc(FLAT_CAP * sizeof(FlatCand))); LB(d_ncand.alloc(4));
+    for (int k = 0; k < 2; k++) { LB(d_keys[k].alloc((size_t)n * 8)); LB(d_vals[k].alloc((size_t)n * 4)); }
+    const uint32_t scene0[6] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u };
+    LB(hipMemcpyAsync(d_scene.p, scene0, sizeof scene0, hipMemcpyHostToDevice, stream));
+    LB(hipMemsetAsync(d_ncand.p, 0, 4, stream));
+    hipLaunchKernelGGL(k_lbvh_bounds, dim3(blocks_for(n)), dim3(256), 0, stream, d_s.as<kl_sphere>(), ns, d_q.as<kl_quad>(), nq, d_t.as<kl_tri>(), nt,
+                       d_blo.as<float4>(), d_bhi.as<float4>(), d_scene.as<uint32_t>());
+    hipLaunchKernelGGL(k_lbvh_keys, dim3(blocks_for(n)), dim3(256), 0, stream, d_blo.as<float4>(), d_bhi.as<float4>(), n, d_scene.as<uint32_t>(),
+                       max_flat ? flat_fraction : 0.0f, d_cand.as<FlatCand>(), d_ncand.as<uint32_t>(), d_keys[0].as<unsigned long long>(), d_vals[0].as<uint32_t>());
+    // which candidates are flat: all of them, the max_flat largest, or (more candidates than the list holds) none
+    uint32_t ncand = 0;
+    LB(hipMemcpyAsync(&ncand, d_ncand.p, 4, hipMemcpyDeviceToHost, stream));
+    LB(hipStreamSynchronize(stream));
+    std::vector<uint32_t> flat;
+    if (ncand > 0 && ncand <= FLAT_CAP) {
+        std::vector<FlatCand> cand(ncand);
+        LB(hipMemcpy(cand.data(), d_cand.p, ncand * sizeof(FlatCand), hipMemcpyDeviceToHost));
+        std::sort(cand.begin(), cand.end(), [](const FlatCand &a, const FlatCand &b) { return a.area != b.area ? a.area > b.area : a.prim < b.prim; });
+        if (cand.size() > max_flat) cand.resize(max_flat);
+        for (const FlatCand &c : cand) flat.push_back(c.prim);
+    }
+    const uint32_t nflat = (uint32_t)flat.size();
+    if (nflat) {
+        LB(d_flat.alloc(nflat * 4));
+        LB(hipMemcpyAsync(d_flat.p, flat.data(), nflat * 4, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_lbvh_mark_flat, dim3(blocks_for(nflat)), dim3(256), 0, stream, d_flat.as<uint32_t>(), nflat, d_keys[0].as<unsigned long long>());
+    }
+    const uint32_t n_tree = n - nflat;
+    // Morton order
+    size_t tmp_bytes = 0;
+    LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys[0].as<unsigned long long>(), d_keys[1].as<unsigned long long>(),
+                                          d_vals[0].as<uint32_t>(), d_vals[1].as<uint32_t>(), (int)n, 0, 64, stream));
+    size_t scan_bytes = 0;
+    LB(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, stream));
+    LB(d_tmp.alloc(std::max(tmp_bytes, scan_bytes)));
+    LB(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_keys[0].as<unsigned long long>(), d_keys[1].as<unsigned long long>(),
+                                          d_vals[0].as<uint32_t>(), d_vals[1].as<uint32_t>(), (int)n, 0, 64, stream));
+    const unsigned long long *keys = d_keys[1].as<unsigned long long>();
+    const uint32_t *vals = d_vals[1].as<uint32_t>();
+    // per-type leaf orders; d_vals[0] and d_keys[0] are free again and serve as scratch
+    Buf d_f[3], d_r[3], d_ord[3], d_leafref;
+    for (int k = 0; k < 3; k++) { LB(d_f[k].alloc((size_t)n * 4)); LB(d_r[k].alloc((size_t)n * 4)); }
+    LB(d_ord[0].alloc((size_t)ns * 4)); LB(d_ord[1].alloc((size_t)nq * 4)); LB(d_ord[2].alloc((size_t)nt * 4));
+    LB(d_leafref.alloc((size_t)n * 4));
+    hipLaunchKernelGGL(k_lbvh_typeflags, dim3(blocks_for(n)), dim3(256), 0, stream, vals, n, ns, nq, d_f[0].as<uint32_t>(), d_f[1].as<uint32_t>(), d_f[2].as<uint32_t>());
+    for (int k = 0; k < 3; k++)
+        LB(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, scan_bytes, d_f[k].as<uint32_t>(), d_r[k].as<uint32_t>(), (int)n, stream));
+    hipLaunchKernelGGL(k_lbvh_orders, dim3(blocks_for(n)), dim3(256), 0, stream, vals, n, ns, nq, d_r[0].as<uint32_t>(), d_r[1].as<uint32_t>(), d_r[2].as<uint32_t>(),
+                       d_ord[0].as<uint32_t>(), d_ord[1].as<uint32_t>(), d_ord[2].as<uint32_t>(), d_leafref.as<int>());
+    // tree over the first n_tree positions
+    Buf d_left, d_right, d_pint, d_pleaf, d_depth, d_maxdepth, d_ilo, d_ihi, d_src, d_alloc, d_nodes4;
+    uint32_t count4 = 0, depth4 = 0, maxdepth = 0;
+    int32_t root4 = NODE_DONE;
+    if (n_tree == 1) {
+        LB(hipMemcpyAsync(&root4, d_leafref.p, 4, hipMemcpyDeviceToHost, stream));
+        LB(hipStreamSynchronize(stream));
+    } else if (n_tree >= 2) {
+        const uint32_t n_int = n_tree - 1;
+        LB(d_left.alloc((size_t)n_int * 4)); LB(d_right.alloc((size_t)n_int * 4)); LB(d_pint.alloc((size_t)n_int * 4)); LB(d_pleaf.alloc((size_t)n_tree * 4));
+        LB(d_depth.alloc((size_t)n_int * 4)); LB(d_maxdepth.alloc(4)); LB(d_ilo.alloc((size_t)n_int * 16)); LB(d_ihi.alloc((size_t)n_int * 16));
+        LB(d_src.alloc((size_t)n_int * 4)); LB(d_alloc.alloc(4)); LB(d_nodes4.alloc((size_t)n_int * 64));
+        LB(hipMemsetAsync(d_maxdepth.p, 0, 4, stream));
+        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(blocks_for(n_int)), dim3(256), 0, stream, keys, (int)n_tree, d_left.as<int>(), d_right.as<int>(),
+                           d_pint.as<int>(), d_pleaf.as<int>());
+        hipLaunchKernelGGL(k_lbvh_depth, dim3(blocks_for(n_int)), dim3(256), 0, stream, d_pint.as<int>(), n_int, d_depth.as<uint32_t>(), d_maxdepth.as<uint32_t>());
+        LB(hipMemcpyAsync(&maxdepth, d_maxdepth.p, 4, hipMemcpyDeviceToHost, stream));
+        LB(hipStreamSynchronize(stream));
+        if (maxdepth >= WALK_CAP) { err = "radix tree deeper than the builder's walk bound"; return LBVH_TOO_DEEP; }
+        for (uint32_t level = maxdepth + 1; level-- > 0;)
+            hipLaunchKernelGGL(k_lbvh_refit, dim3(blocks_for(n_int)), dim3(256), 0, stream, level, d_depth.as<uint32_t>(), n_int, d_left.as<int>(), d_right.as<int>(),
+                               vals, d_blo.as<float4>(), d_bhi.as<float4>(), d_ilo.as<float4>(), d_ihi.as<float4>());
+        // collapse, level by level from the root (4-wide node 0 = binary node 0)
+        const int zero = 0; const uint32_t one = 1;
+        LB(hipMemcpyAsync(d_src.p, &zero, 4, hipMemcpyHostToDevice, stream));
+        LB(hipMemcpyAsync(d_alloc.p, &one, 4, hipMemcpyHostToDevice, stream));
+        uint32_t begin = 0, end = 1;
+        while (begin < end) {
+            depth4++;
+            if (depth4 > (uint32_t)BVH_MAX_DEPTH) { LB(hipStreamSynchronize(stream)); err = "tree deeper than the traversal stack allows"; return LBVH_TOO_DEEP; }
+            hipLaunchKernelGGL(k_lbvh_collapse, dim3(blocks_for(end - begin)), dim3(256), 0, stream, begin, end, d_src.as<int>(), d_alloc.as<uint32_t>(),
+                               d_left.as<int>(), d_right.as<int>(), d_leafref.as<int>(), vals, d_blo.as<float4>(), d_bhi.as<float4>(),
+                               d_ilo.as<float4>(), d_ihi.as<float4>(), d_nodes4.as<uint32_t>());
+            uint32_t total = 0;
+            LB(hipMemcpyAsync(&total, d_alloc.p, 4, hipMemcpyDeviceToHost, stream));
+            LB(hipStreamSynchronize(stream));
+            if (total > n_int) { err = "4-wide node count exceeds the binary node count"; return LBVH_HIP_ERROR; }
+            begin = end; end = total;
+        }
+        count4 = end; root4 = 0;
+    }
+    LB(hipGetLastError());
+    // results to the host
+    out.nodes4.resize((size_t)count4 * 16);
+    if (count4) LB(hipMemcpyAsync(out.nodes4.data(), d_nodes4.p, (size_t)count4 * 64, hipMemcpyDeviceToHost, stream));
+    out.sph_order.resize(ns); out.quad_order.resize(nq); out.tri_order.resize(nt);
+    if (ns) LB(hipMemcpyAsync(out.sph_order.data(), d_ord[0].p, (size_t)ns * 4, hipMemcpyDeviceToHost, stream));
+    if (nq) LB(hipMemcpyAsync(out.quad_order.data(), d_ord[1].p, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+    if (nt) LB(hipMemcpyAsync(out.tri_order.data(), d_ord[2].p, (size_t)nt * 4, hipMemcpyDeviceToHost, stream));
+    LB(hipStreamSynchronize(stream));
+#undef LB
+    out.root4 = root4; out.depth4 = depth4;
+    // the flat primitives sorted last, so they close each order array
+    uint32_t fc[3] = { 0, 0, 0 };
+    for (uint32_t g : flat) fc[g < ns ? PRIM_SPHERE : (g < ns + nq ? PRIM_QUAD : PRIM_TRI)]++;
+    const uint32_t cnt[3] = { ns, nq, nt };
+    for (int k = 0; k < 3; k++) { out.flat_count[k] = fc[k]; out.flat_start[k] = cnt[k] - fc[k]; }
+    out.stats.nodes = count4; out.stats.leaves = n_tree; out.stats.max_depth = depth4; out.stats.max_leaf_size = n_tree ? 1u : 0u;
+    out.stats.sah_cost = 0.0f;
+    out.stats.node_bytes = (uint64_t)count4 * 64u;
+    out.stats.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return LBVH_OK;
+}
+
+}  // namespace kl

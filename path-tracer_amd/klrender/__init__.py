@@ -21,6 +21,7 @@ TEX_HDRI, TEX_ALBEDO = 0, 1
 TONEMAP_CLAMP, TONEMAP_ACES = 0, 1
 ACCUM_MEAN, ACCUM_SUM = 0, 1
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
+BUILD_HOST_SAH, BUILD_GPU_LBVH = 0, 1
 CONTINUE = 0xFFFFFFFF
 MISS = 0xFFFFFFFF
 
@@ -42,7 +43,7 @@ class Params(C.Structure):
                 ("max_dist", C.c_float), ("ao_length", C.c_float), ("hdri_strength", C.c_float),
                 ("accel", C.c_uint32), ("frames_in_flight", C.c_uint32), ("fused_compaction", C.c_uint32),
                 ("collect_stats", C.c_uint32), ("profile_kernels", C.c_uint32), ("batch_lanes", C.c_uint32),
-                ("trace_primary_per_frame", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("trace_primary_per_frame", C.c_uint32), ("bvh_builder", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 class Counters(C.Structure):
@@ -59,7 +60,7 @@ class BvhStats(C.Structure):
     _fields_ = [("nodes", C.c_uint32), ("leaves", C.c_uint32), ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32),
                 ("spheres", C.c_uint32), ("quads", C.c_uint32), ("tris", C.c_uint32), ("sah_cost", C.c_float),
                 ("build_seconds", C.c_double), ("node_bytes", C.c_uint64), ("prim_bytes", C.c_uint64),
-                ("flat_spheres", C.c_uint32), ("flat_quads", C.c_uint32), ("flat_tris", C.c_uint32), ("reserved", C.c_uint32)]
+                ("flat_spheres", C.c_uint32), ("flat_quads", C.c_uint32), ("flat_tris", C.c_uint32), ("builder", C.c_uint32)]
 
 
 class SynthParams(C.Structure):

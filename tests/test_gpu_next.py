@@ -104,3 +104,89 @@ def test_mesh_file_scene_renders_like_the_oracle(tmp_path, textures):
     sc.set_texture(ko.TEX_HDRI, textures["hdri"]); sc.set_texture(ko.TEX_ALBEDO, textures["albedo"])
     pr = ko.default_params(width=w, height=h, mode=ko.MODE_PT, max_frames=0, max_bounces=6, use_bvh=1)
     assert_bitexact(got, ko.render_mean(sc, ko.default_camera(), pr, 2), "scene from a mesh file")
+
+
+# ---------------------------------------------------------------- GPU-side BVH build
+def _trace_both(r, o, d):
+    r.update_params(accel=kl.ACCEL_BVH)
+    tb = r.trace_rays(o, d)
+    r.update_params(accel=kl.ACCEL_BRUTE)
+    tf = r.trace_rays(o, d)
+    return tb, tf
+
+
+def test_gpu_built_tree_finds_the_same_hits():
+    """the Morton-ordered tree built on the GPU against the flat loop and against the host SAH tree: same primitive,
+    same t and uv bit for bit (the closest hit does not depend on the tree), degenerate inputs included"""
+    from test_gpu_scene import random_rays
+    s, q, t, m = kl.synth_scene(blobs=24, tris_per_blob=160, analytic_spheres=40, seed=3)
+    o, d = random_rays(3000, 13)
+    o[:50] = t["v0"][:50]
+    d[50:60] = np.eye(3, dtype=np.float32)[np.arange(10) % 3]
+    with kl.Renderer(8, 8) as r:
+        r.update_params(bvh_builder=kl.BUILD_GPU_LBVH)
+        r.upload_scene(s, q, t, m)
+        st = r.bvh_stats()
+        assert st.builder == kl.BUILD_GPU_LBVH and st.max_leaf_size == 1
+        assert (st.spheres, st.quads, st.tris) == (len(s), len(q), len(t))
+        assert st.flat_quads == 7 and st.leaves == len(s) + len(q) + len(t) - 7       # the room's walls stay out of the tree
+        assert 1 <= st.nodes <= st.leaves - 1 and st.max_depth <= 32 and st.node_bytes == st.nodes * 64
+        (tb, pb, ub), (tf, pf, uf) = _trace_both(r, o, d)
+        r.update_params(bvh_builder=kl.BUILD_HOST_SAH, accel=kl.ACCEL_BVH)
+        r.upload_scene(s, q, t, m)
+        assert r.bvh_stats().builder == kl.BUILD_HOST_SAH
+        th, ph, uh = r.trace_rays(o, d)
+    assert np.array_equal(pb, pf) and np.array_equal(ph, pf) and (pf != kl.MISS).mean() > 0.9
+    assert_bitexact(tb, tf, "t: GPU-built tree vs flat loop"); assert_bitexact(ub, uf, "uv: GPU-built tree vs flat loop")
+    assert_bitexact(th, tf, "t: host tree vs flat loop")
+    # many primitives in one Morton cell (exact duplicates) and a degenerate zero-area triangle
+    dup = np.zeros(3000, dtype=kl.tri_dtype)
+    dup["v0"] = (0.0, 1.0, -3.0); dup["v1"] = (0.5, 1.0, -3.0); dup["v2"] = (0.0, 1.5, -3.0)
+    dup[-1]["v1"] = dup[-1]["v0"]
+    dup["material"] = 0
+    mats = np.zeros(1, dtype=kl.material_dtype); mats["type"] = kl.DIFFUSE; mats["color"] = 0.5; mats["roughness"] = 1.0
+    o2 = np.tile(np.array([[0.1, 1.1, 2.0]], dtype=np.float32), (64, 1)); d2 = np.tile(np.array([[0, 0, -1]], dtype=np.float32), (64, 1))
+    with kl.Renderer(8, 8) as r:
+        r.update_params(bvh_builder=kl.BUILD_GPU_LBVH)
+        r.upload_scene(None, None, dup, mats)
+        assert r.bvh_stats().builder == kl.BUILD_GPU_LBVH
+        (tb, pb, ub), (tf, pf, uf) = _trace_both(r, o2, d2)
+    assert np.all(pb == 0) and np.array_equal(pb, pf)              # exact ties: the lowest declaration-order id wins
+    assert_bitexact(tb, tf, "duplicates: t")
+
+
+def test_gpu_built_tree_renders_like_the_oracle(textures):
+    s, q, t, m = kl.synth_scene(blobs=24, tris_per_blob=160, analytic_spheres=40, seed=3)
+    sc = ko.Scene(s, q, t, m)
+    sc.set_texture(ko.TEX_HDRI, textures["hdri"]); sc.set_texture(ko.TEX_ALBEDO, textures["albedo"])
+    w, h = 128, 72
+    with kl.Renderer(w, h) as r:
+        r.update_params(bvh_builder=kl.BUILD_GPU_LBVH, max_bounces=8, max_frames=0, accel=kl.ACCEL_BVH)
+        r.upload_scene(s, q, t, m)
+        r.upload_texture(kl.TEX_HDRI, textures["hdri"]); r.upload_texture(kl.TEX_ALBEDO, textures["albedo"])
+        r.render_frames(3)
+        acc = r.read_accum()
+    p = ko.default_params(width=w, height=h, mode=ko.MODE_PT, max_frames=0, max_bounces=8, use_bvh=1)
+    assert_bitexact(acc, ko.render_mean(sc, ko.default_camera(), p, 3), "GPU-built tree, path traced")
+
+
+def test_gpu_build_of_a_million_triangles():
+    """BASELINE config 3's scene: the GPU build against the host build on the same rays"""
+    from test_gpu_scene import random_rays
+    s, q, t, m = kl.synth_scene(blobs=1000, tris_per_blob=1000, seed=1)
+    o, d = random_rays(20000, 7)
+    with kl.Renderer(8, 8) as r:
+        r.update_params(bvh_builder=kl.BUILD_GPU_LBVH, accel=kl.ACCEL_BVH)
+        r.upload_scene(s, q, t, m)
+        st = r.bvh_stats()
+        assert st.builder == kl.BUILD_GPU_LBVH and st.tris == 1_000_000 and st.max_depth <= 32
+        tg, pg, ug = r.trace_rays(o, d)
+        gpu_seconds = st.build_seconds
+        r.update_params(bvh_builder=kl.BUILD_HOST_SAH)
+        r.upload_scene(s, q, t, m)
+        th, ph, uh = r.trace_rays(o, d)
+        host_seconds = r.bvh_stats().build_seconds
+    assert np.array_equal(pg, ph)
+    assert_bitexact(tg, th, "1M triangles: GPU-built vs host-built tree, t"); assert_bitexact(ug, uh, "uv")
+    print("build of 1M triangles: GPU %.4f s, host %.4f s" % (gpu_seconds, host_seconds))
+    assert gpu_seconds < host_seconds
