@@ -651,8 +651,11 @@ __device__ __forceinline__ ShadeIn shade_load(const RayQueue &q, const float4 *h
 // hit record -> ONE shading record (surface and material together) -> texel. The next iteration's queue entry
 // is requested before this iteration's work starts, and the queue-tail atomic is issued as soon as the lanes
 // know whether they go on, so that its round trip runs under the flat-primitive tests.
+#ifndef KL_SHADE_MIN_WAVES
+#define KL_SHADE_MIN_WAVES 1
+#endif
 template <int MODE>
-__global__ __launch_bounds__(256) void k_shade(SceneDev sc, FrameDev f, RayQueue qin, const float4 *hits,
+__global__ __launch_bounds__(256, KL_SHADE_MIN_WAVES) void k_shade(SceneDev sc, FrameDev f, RayQueue qin, const float4 *hits,
                                                const uint32_t *counts_in, RayQueue qout, uint32_t *counts_out,
                                                float4 *raw, uint32_t bounce, uint32_t fused, float4 *hits_out) {
     // block b works on segment b % nseg; survivors stay in their segment
