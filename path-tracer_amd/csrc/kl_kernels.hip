@@ -395,12 +395,22 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
         // ---- refill idle lanes from the wave's reserved range
         unsigned long long idle = __ballot(!active);
         if (idle != 0ull && !(exhausted && cur == end)) {
+            float touch0 = 0.0f, touch1 = 0.0f, touch2 = 0.0f; bool touched = false;
             if (cur == end) {
                 uint32_t base = 0u;
                 if (lane == 0) base = atomicAdd(head, ISECT_CHUNK);
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= count) { exhausted = true; }
-                else { cur = base; end = min(base + ISECT_CHUNK, count); }
+                else {
+                    cur = base; end = min(base + ISECT_CHUNK, count);
+                    // the whole chunk's queue lines are requested now, together with this refill's own loads (one
+                    // wait for both): the chunk's later refills then find their rays in L2 instead of HBM
+                    const uint32_t tr = seg_base + min(base + lane, count - 1u);
+                    touch0 = ((const float *)(q.od + tr))[0];
+                    touch1 = ((const float *)(q.d2 + tr))[0];
+                    if (seeded) touch2 = ((const float *)(hits + tr))[0];
+                    touched = true;
+                }
             }
             uint32_t avail = end - cur;
             uint32_t want = (uint32_t)__popcll(idle);
@@ -431,6 +441,7 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                 }
             }
             cur += take;
+            if (touched) asm volatile("" :: "v"(touch0), "v"(touch1), "v"(touch2));   // keeps the requests; their values are not used
         }
         unsigned long long am = __ballot(active);
         if (am == 0ull) { if (exhausted && cur == end) break; else continue; }
