@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <thread>
@@ -332,6 +333,18 @@ kl_status render_batch(kl_ctx *c, BatchLane &L, hipEvent_t after, uint32_t first
     return KL_OK;
 }
 
+// splits [0, n) over up to `threads` host threads (record packing of million-primitive scenes)
+template <typename F> void parallel_for(uint32_t n, unsigned threads, F body) {
+    if (threads <= 1 || n < 65536u) { body(0u, n); return; }
+    std::vector<std::thread> pool;
+    const uint32_t per = (n + threads - 1) / threads;
+    for (unsigned k = 0; k < threads; k++) {
+        const uint32_t b = std::min<uint64_t>((uint64_t)k * per, n), e = std::min<uint64_t>((uint64_t)b + per, n);
+        if (b < e) pool.emplace_back([=, &body]() { body(b, e); });
+    }
+    for (std::thread &t : pool) t.join();
+}
+
 template <typename T> kl_status upload(kl_ctx *c, DevBuf<T> &buf, const void *src, size_t count) {
     KL_HIP(c, buf.alloc(std::max<size_t>(count, 1)));
     if (count) KL_HIP(c, hipMemcpyAsync(buf.p, src, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
@@ -542,9 +555,14 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     const uint32_t base[3] = { n_nodes, n_nodes + ns, n_nodes + ns + nq };
     const size_t n_rec = std::max<size_t>((size_t)n_nodes + ns + nq + nt, 1);   // record 0 always exists
     if (n_rec >= MAX_RECORDS) return fail(c, KL_E_LIMIT, "nodes + primitives exceed 2^26 records");
-    std::vector<float4> rec(n_rec * 4, make_float4(0, 0, 0, 0));
+    // (plain arrays: every word is written by the packing loops below, a zero fill of a gigabyte first would cost as much as they do)
+    const float4 zero4 = make_float4(0, 0, 0, 0);
+    std::unique_ptr<float4[]> rec(new (std::nothrow) float4[n_rec * 4]);
     // shading records (layout: kl_types.hpp), one per primitive in record order
-    std::vector<float4> shrec(std::max<size_t>((size_t)ns + nq + nt, 1) * 4, make_float4(0, 0, 0, 0));
+    const size_t n_shrec = std::max<size_t>((size_t)ns + nq + nt, 1);
+    std::unique_ptr<float4[]> shrec(new (std::nothrow) float4[n_shrec * 4]);
+    if (!rec || !shrec) return fail(c, KL_E_NOMEM, "host memory for the scene records");
+    for (int k = 0; k < 4; k++) { rec[k] = zero4; shrec[k] = zero4; }      // record 0 exists even in an empty scene
     auto shade_rec = [&](size_t prim, v3 n, const kl_material &mt, float4 s2, float4 s3) {
         float4 *r = &shrec[4 * prim];
         r[0] = make_float4(n.x, n.y, n.z, bits((uint32_t)mt.type));
@@ -557,42 +575,52 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
         uint32_t lv = (uint32_t)~child, type = (lv >> 29) & 3u, cnt = ((lv >> 26) & 7u) + 1u, start = lv & 0x3FFFFFFu;
         return make_leaf(type, base[type] + start, cnt);
     };
-    for (uint32_t k = 0; k < n_nodes; k++) {
-        uint32_t w[16]; std::memcpy(w, &bvh.nodes4[(size_t)k * 16], sizeof w);
-        for (int j = 12; j < 16; j++) w[j] = (uint32_t)patch_child((int32_t)w[j]);
-        std::memcpy(&rec[4 * (size_t)k], w, sizeof w);
-    }
+    parallel_for(n_nodes, threads, [&](uint32_t kb, uint32_t ke) {
+        for (uint32_t k = kb; k < ke; k++) {
+            uint32_t w[16]; std::memcpy(w, &bvh.nodes4[(size_t)k * 16], sizeof w);
+            for (int j = 12; j < 16; j++) w[j] = (uint32_t)patch_child((int32_t)w[j]);
+            std::memcpy(&rec[4 * (size_t)k], w, sizeof w);
+        }
+    });
     const int32_t tree_root = bvh.root4;
     bvh.stats.nodes = n_nodes; bvh.stats.max_depth = bvh.depth4; bvh.stats.node_bytes = (uint64_t)n_nodes * 64u;
     bvh.stats.builder = builder;
-    for (uint32_t k = 0; k < ns; k++) {
-        const kl_sphere &x = s[bvh.sph_order[k]];
-        float4 *r = &rec[4 * ((size_t)base[PRIM_SPHERE] + k)];
-        r[0] = make_float4(x.center[0], x.center[1], x.center[2], x.radius);
-        r[1] = make_float4(bits(bvh.sph_order[k]), bits(x.material), 0.0f, 0.0f);
-        shade_rec(k, V(x.center[0], x.center[1], x.center[2]), m[x.material], make_float4(0, 0, x.radius, 0.0f), make_float4(0, 0, 0, 0));
-    }
-    for (uint32_t k = 0; k < nq; k++) {
-        const kl_quad &x = q[bvh.quad_order[k]];
-        float4 *r = &rec[4 * ((size_t)base[PRIM_QUAD] + k)];
-        r[0] = make_float4(x.v0[0], x.v0[1], x.v0[2], x.v1[0]);
-        r[1] = make_float4(x.v1[1], x.v1[2], x.v2[0], x.v2[1]);
-        r[2] = make_float4(x.v2[2], x.v3[0], x.v3[1], x.v3[2]);
-        r[3] = make_float4(bits(ns + bvh.quad_order[k]), bits(x.material), 0.0f, 0.0f);
-        v3 v1 = V(x.v1[0], x.v1[1], x.v1[2]), v2 = V(x.v2[0], x.v2[1], x.v2[2]), v3_ = V(x.v3[0], x.v3[1], x.v3[2]);
-        shade_rec((size_t)ns + k, normalize(cross(v2 - v1, v3_ - v1)), m[x.material], make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0));   // RawFrame.glsl:319
-    }
-    for (uint32_t k = 0; k < nt; k++) {
-        const kl_tri &x = t[bvh.tri_order[k]];
-        v3 v0 = V(x.v0[0], x.v0[1], x.v0[2]);
-        v3 e1 = V(x.v1[0], x.v1[1], x.v1[2]) - v0, e2 = V(x.v2[0], x.v2[1], x.v2[2]) - v0;
-        v3 nor = normalize(cross(e1, e2));       // the flat shading normal, in the arithmetic the shade stage would use
-        float4 *r = &rec[4 * ((size_t)base[PRIM_TRI] + k)];
-        r[0] = make_float4(v0.x, v0.y, v0.z, e1.x);
-        r[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-        r[2] = make_float4(e2.z, bits(ns + nq + bvh.tri_order[k]), bits(x.material), 0.0f);
-        shade_rec((size_t)ns + nq + k, nor, m[x.material], make_float4(0, 0, x.uv0[0], x.uv0[1]), make_float4(x.uv1[0], x.uv1[1], x.uv2[0], x.uv2[1]));
-    }
+    parallel_for(ns, threads, [&](uint32_t kb, uint32_t ke) {
+        for (uint32_t k = kb; k < ke; k++) {
+            const kl_sphere &x = s[bvh.sph_order[k]];
+            float4 *r = &rec[4 * ((size_t)base[PRIM_SPHERE] + k)];
+            r[0] = make_float4(x.center[0], x.center[1], x.center[2], x.radius);
+            r[1] = make_float4(bits(bvh.sph_order[k]), bits(x.material), 0.0f, 0.0f);
+            r[2] = zero4; r[3] = zero4;
+            shade_rec(k, V(x.center[0], x.center[1], x.center[2]), m[x.material], make_float4(0, 0, x.radius, 0.0f), make_float4(0, 0, 0, 0));
+        }
+    });
+    parallel_for(nq, threads, [&](uint32_t kb, uint32_t ke) {
+        for (uint32_t k = kb; k < ke; k++) {
+            const kl_quad &x = q[bvh.quad_order[k]];
+            float4 *r = &rec[4 * ((size_t)base[PRIM_QUAD] + k)];
+            r[0] = make_float4(x.v0[0], x.v0[1], x.v0[2], x.v1[0]);
+            r[1] = make_float4(x.v1[1], x.v1[2], x.v2[0], x.v2[1]);
+            r[2] = make_float4(x.v2[2], x.v3[0], x.v3[1], x.v3[2]);
+            r[3] = make_float4(bits(ns + bvh.quad_order[k]), bits(x.material), 0.0f, 0.0f);
+            v3 v1 = V(x.v1[0], x.v1[1], x.v1[2]), v2 = V(x.v2[0], x.v2[1], x.v2[2]), v3_ = V(x.v3[0], x.v3[1], x.v3[2]);
+            shade_rec((size_t)ns + k, normalize(cross(v2 - v1, v3_ - v1)), m[x.material], make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0));   // RawFrame.glsl:319
+        }
+    });
+    parallel_for(nt, threads, [&](uint32_t kb, uint32_t ke) {
+        for (uint32_t k = kb; k < ke; k++) {
+            const kl_tri &x = t[bvh.tri_order[k]];
+            v3 v0 = V(x.v0[0], x.v0[1], x.v0[2]);
+            v3 e1 = V(x.v1[0], x.v1[1], x.v1[2]) - v0, e2 = V(x.v2[0], x.v2[1], x.v2[2]) - v0;
+            v3 nor = normalize(cross(e1, e2));       // the flat shading normal, in the arithmetic the shade stage would use
+            float4 *r = &rec[4 * ((size_t)base[PRIM_TRI] + k)];
+            r[0] = make_float4(v0.x, v0.y, v0.z, e1.x);
+            r[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+            r[2] = make_float4(e2.z, bits(ns + nq + bvh.tri_order[k]), bits(x.material), 0.0f);
+            r[3] = zero4;
+            shade_rec((size_t)ns + nq + k, nor, m[x.material], make_float4(0, 0, x.uv0[0], x.uv0[1]), make_float4(x.uv1[0], x.uv1[1], x.uv2[0], x.uv2[1]));
+        }
+    });
     // ray-independent terms of the quad test (RawFrame.glsl:219-244) for the flat quads, in the test's own operations
     const uint32_t nfq = bvh.flat_count[PRIM_QUAD];
     std::vector<float4> flatq((size_t)nfq * 5);
@@ -617,8 +645,8 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     }
     kl_status st;
     if ((st = upload(c, c->d_flatq, flatq.data(), flatq.size())) != KL_OK) return st;
-    if ((st = upload(c, c->d_rec, rec.data(), rec.size())) != KL_OK) return st;
-    if ((st = upload(c, c->d_shrec, shrec.data(), shrec.size())) != KL_OK) return st;
+    if ((st = upload(c, c->d_rec, rec.get(), n_rec * 4)) != KL_OK) return st;
+    if ((st = upload(c, c->d_shrec, shrec.get(), n_shrec * 4)) != KL_OK) return st;
     KL_HIP(c, hipStreamSynchronize(c->stream));     // the host vectors go out of scope below
     c->sc.rec = c->d_rec.p; c->sc.root = patch_child(tree_root); c->sc.n_nodes = n_nodes;
     c->sc.shrec = c->d_shrec.p; c->sc.flatq = c->d_flatq.p;
