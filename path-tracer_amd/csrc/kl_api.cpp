@@ -445,6 +445,7 @@ kl_status kl_destroy(kl_ctx *c) {
 
 kl_status kl_resize(kl_ctx *c, uint32_t width, uint32_t height) {
     if (!c || width == 0 || height == 0 || width > KL_MAX_DIM || height > KL_MAX_DIM) return fail(c, KL_E_INVALID, "bad size");
+    KL_HIP(c, hipSetDevice(c->device));
     KL_HIP(c, hipStreamSynchronize(c->stream));
     c->width = width; c->height = height;
     compute_local(c);
@@ -456,6 +457,7 @@ kl_status kl_recompile(kl_ctx *c) { if (!c) return KL_E_INVALID; soft_reset(c); 
 kl_status kl_reset(kl_ctx *c) {
     if (!c) return KL_E_INVALID;
     soft_reset(c);
+    KL_HIP(c, hipSetDevice(c->device));
     // a fresh accumulation: frame 0 then yields exactly the raw frame even if a stale texel was non-finite
     if (c->d_acc.p) KL_HIP(c, hipMemsetAsync(c->d_acc.p, 0, c->d_acc.n * sizeof(float4), c->stream));
     return KL_OK;
@@ -480,6 +482,7 @@ kl_status kl_set_params(kl_ctx *c, const kl_params *p) {
     if (p->bvh_builder > KL_BUILD_GPU_LBVH) return fail(c, KL_E_INVALID, "bad bvh_builder");
     if (p->batch_lanes > KL_MAX_BATCH_LANES) return fail(c, KL_E_LIMIT, "batch_lanes must be <= 4");
     if (!(p->max_dist > 0.0f) || !(p->eps >= 0.0f)) return fail(c, KL_E_INVALID, "bad eps/max_dist");
+    KL_HIP(c, hipSetDevice(c->device));
     KL_HIP(c, hipStreamSynchronize(c->stream));
     c->params = *p;
     return KL_OK;
@@ -750,6 +753,7 @@ kl_status kl_render_frames(kl_ctx *c, uint32_t n, uint32_t first_frame) {
 
 kl_status kl_synchronize(kl_ctx *c) {
     if (!c) return KL_E_INVALID;
+    KL_HIP(c, hipSetDevice(c->device));
     KL_HIP(c, hipStreamSynchronize(c->stream));
     return KL_OK;
 }
@@ -758,6 +762,7 @@ static kl_status read_buf(kl_ctx *c, const DevBuf<float4> &b, float *rgba, size_
     if (!c || !rgba) return fail(c, KL_E_INVALID, "null output");
     if (!b.p || b.n != c->npl) return fail(c, KL_E_STATE, "nothing rendered yet");
     if (bytes != (size_t)c->npl * 16) return fail(c, KL_E_INVALID, "output must be local_rows x width x 16 bytes");
+    KL_HIP(c, hipSetDevice(c->device));
     KL_HIP(c, hipMemcpyAsync(rgba, b.p, bytes, hipMemcpyDeviceToHost, c->stream));
     KL_HIP(c, hipStreamSynchronize(c->stream));
     return KL_OK;
@@ -769,6 +774,7 @@ kl_status kl_resolve(kl_ctx *c, uint32_t tonemap, uint8_t *rgba8, size_t bytes) 
     if (!c || !rgba8 || tonemap > KL_TONEMAP_ACES) return fail(c, KL_E_INVALID, "bad resolve arguments");
     if (!c->d_acc.p || c->d_acc.n != c->npl) return fail(c, KL_E_STATE, "nothing rendered yet");
     if (bytes != (size_t)c->npl * 4) return fail(c, KL_E_INVALID, "output must be local_rows x width x 4 bytes");
+    KL_HIP(c, hipSetDevice(c->device));
     KL_HIP(c, c->d_resolve.alloc(c->npl));
     launch_resolve(c->stream, c->lc, c->d_acc.p, c->d_resolve.p, c->npl, tonemap);
     KL_HIP(c, hipMemcpyAsync(rgba8, c->d_resolve.p, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -780,6 +786,7 @@ kl_status kl_get_counters(kl_ctx *c, kl_counters *out) {
     if (!c || !out) return KL_E_INVALID;
     std::memset(out, 0, sizeof *out);
     out->frames = c->frames_total; out->paths = c->paths_total;
+    KL_HIP(c, hipSetDevice(c->device));
     if (c->d_counters.p) {
         Counters h;
         KL_HIP(c, hipMemcpyAsync(&h, c->d_counters.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -791,6 +798,7 @@ kl_status kl_get_counters(kl_ctx *c, kl_counters *out) {
 }
 kl_status kl_reset_counters(kl_ctx *c) {
     if (!c) return KL_E_INVALID;
+    KL_HIP(c, hipSetDevice(c->device));
     c->frames_total = 0; c->paths_total = 0;
     drain_events(c);
     std::memset(&c->timing, 0, sizeof c->timing);
@@ -799,6 +807,7 @@ kl_status kl_reset_counters(kl_ctx *c) {
 }
 kl_status kl_get_timing(kl_ctx *c, kl_timing *out) {
     if (!c || !out) return KL_E_INVALID;
+    KL_HIP(c, hipSetDevice(c->device));
     drain_events(c);
     *out = c->timing;
     return KL_OK;
@@ -845,6 +854,7 @@ kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, f
 
 kl_status kl_set_shard(kl_ctx *c, uint32_t rank, uint32_t world, uint32_t band_rows) {
     if (!c || world == 0 || rank >= world || band_rows == 0) return fail(c, KL_E_INVALID, "need rank < world and band_rows >= 1");
+    KL_HIP(c, hipSetDevice(c->device));
     KL_HIP(c, hipStreamSynchronize(c->stream));
     c->rank = rank; c->world = world; c->band_rows = band_rows;
     compute_local(c);
@@ -862,6 +872,7 @@ kl_status kl_copy_accum_to_device(kl_ctx *c, void *dst, size_t bytes) {
     if (!c || !dst) return fail(c, KL_E_INVALID, "null destination");
     if (!c->d_acc.p || c->d_acc.n != c->npl) return fail(c, KL_E_STATE, "nothing rendered yet");
     if (bytes != (size_t)c->npl * 16) return fail(c, KL_E_INVALID, "size must be local_rows x width x 16 bytes");
+    KL_HIP(c, hipSetDevice(c->device));
     KL_HIP(c, hipMemcpyAsync(dst, c->d_acc.p, bytes, hipMemcpyDeviceToDevice, c->stream));
     KL_HIP(c, hipStreamSynchronize(c->stream));
     return KL_OK;
