@@ -3,6 +3,7 @@
 //
 //   kl_bench --scene builtin --mode pt --w 640 --h 360 --frames 16 --out frame.png
 //   kl_bench --scene synth --blobs 1000 --tris-per-blob 1000 --w 1920 --h 1080 --frames 64 --bounces 8
+//   kl_bench --scene synth --builder gpu ...         (tree built on the GPU instead of the host cores)
 //   kl_bench --scene builtin --interactive-demo      (drives the GLSL_Renderer-shaped host class)
 #include <chrono>
 #include <cstdio>
@@ -20,7 +21,7 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 #define CK(call) do { kl_status s_ = (call); if (s_ != KL_OK) { std::fprintf(stderr, "%s: %s (%s)\n", #call, kl_status_string(s_), ctx ? kl_last_error(ctx) : ""); return 1; } } while (0)
 
 int main(int argc, char **argv) {
-    std::string scene = "builtin", mode = "pt", out, hdri, albedo, albedo_raw;
+    std::string scene = "builtin", mode = "pt", out, hdri, albedo, albedo_raw, builder = "host";
     int araw[3] = {0, 0, 0};
     uint32_t w = 1920, h = 1080, frames = 16, bounces = 0, blobs = 1000, tpb = 1000, spheres = 0, warmup = 1, device = 0, fif = 0;
     bool demo = false;
@@ -35,6 +36,7 @@ int main(int argc, char **argv) {
         else if (a == "--device") device = std::atoi(next()); else if (a == "--frames-in-flight") fif = std::atoi(next());
         else if (a == "--out") out = next(); else if (a == "--hdri") hdri = next(); else if (a == "--albedo") albedo = next();
         else if (a == "--albedo-raw") { albedo_raw = next(); for (int k = 0; k < 3; k++) araw[k] = std::atoi(next()); }
+        else if (a == "--builder") builder = next();
         else if (a == "--interactive-demo") demo = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -55,6 +57,10 @@ int main(int argc, char **argv) {
     kl_ctx *ctx = nullptr;
     CK(kl_create(&ctx, (int)device, w, h));
     kl_bvh_stats bs; std::memset(&bs, 0, sizeof bs);
+    kl_params p; kl_default_params(&p);
+    p.max_frames = 0; if (bounces) p.max_bounces = bounces; p.frames_in_flight = fif;
+    p.bvh_builder = builder == "gpu" ? KL_BUILD_GPU_LBVH : KL_BUILD_HOST_SAH;      // read by the upload below
+    CK(kl_set_params(ctx, &p));
     if (scene == "builtin") {
         CK(kl_load_builtin_scene(ctx));
     } else {
@@ -70,9 +76,6 @@ int main(int argc, char **argv) {
     if (!hdri.empty()) { if (!img.f_load(hdri)) { std::fprintf(stderr, "cannot read %s\n", hdri.c_str()); return 1; } CK(kl_upload_texture(ctx, KL_TEX_HDRI, img.data.data(), img.width, img.height, img.channels)); }
     if (!albedo.empty()) { if (!img.f_load(albedo)) { std::fprintf(stderr, "cannot read %s\n", albedo.c_str()); return 1; } CK(kl_upload_texture(ctx, KL_TEX_ALBEDO, img.data.data(), img.width, img.height, img.channels)); }
     if (!albedo_raw.empty()) { if (!img.f_load_raw(albedo_raw, araw[0], araw[1], araw[2])) { std::fprintf(stderr, "cannot read %s\n", albedo_raw.c_str()); return 1; } CK(kl_upload_texture(ctx, KL_TEX_ALBEDO, img.data.data(), img.width, img.height, img.channels)); }
-    kl_params p; kl_default_params(&p);
-    p.max_frames = 0; if (bounces) p.max_bounces = bounces; p.frames_in_flight = fif;
-    CK(kl_set_params(ctx, &p));
     CK(kl_set_mode(ctx, mode == "ao" ? KL_MODE_AO : (mode == "z" ? KL_MODE_Z : KL_MODE_PT)));
     for (uint32_t i = 0; i < warmup; i++) { CK(kl_reset(ctx)); CK(kl_render_frames(ctx, frames, 0)); }
     CK(kl_synchronize(ctx)); CK(kl_reset_counters(ctx)); CK(kl_reset(ctx));
@@ -82,9 +85,11 @@ int main(int argc, char **argv) {
     double dt = now_s() - t0;
     kl_counters cn; CK(kl_get_counters(ctx, &cn));
     std::printf("{\"scene\": \"%s\", \"mode\": \"%s\", \"w\": %u, \"h\": %u, \"frames\": %u, \"bounces\": %u, \"seconds\": %.6f, "
-                "\"samples_per_s\": %.1f, \"mrays_per_s\": %.2f, \"rays_per_sample\": %.3f, \"bvh_nodes\": %u, \"tris\": %u}\n",
+                "\"samples_per_s\": %.1f, \"mrays_per_s\": %.2f, \"rays_per_sample\": %.3f, \"bvh_nodes\": %u, \"tris\": %u, "
+                "\"bvh_builder\": \"%s\", \"bvh_build_s\": %.4f}\n",
                 scene.c_str(), mode.c_str(), w, h, frames, p.max_bounces, dt, (double)cn.paths / dt, (double)cn.rays / dt / 1e6,
-                (double)cn.rays / (double)(cn.paths ? cn.paths : 1), bs.nodes, bs.tris);
+                (double)cn.rays / (double)(cn.paths ? cn.paths : 1), bs.nodes, bs.tris,
+                bs.builder == KL_BUILD_GPU_LBVH ? "gpu" : "host", bs.build_seconds);
     if (!out.empty()) {
         std::vector<uint8_t> px((size_t)w * h * 4);
         CK(kl_resolve(ctx, KL_TONEMAP_CLAMP, px.data(), px.size()));
