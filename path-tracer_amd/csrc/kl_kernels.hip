@@ -430,7 +430,10 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                 float sx = fabsf(d.x) > 1e-20f ? d.x : copysignf(1e-20f, d.x);
                 float sy = fabsf(d.y) > 1e-20f ? d.y : copysignf(1e-20f, d.y);
                 float sz = fabsf(d.z) > 1e-20f ? d.z : copysignf(1e-20f, d.z);
-                id = V(1.0f / sx, 1.0f / sy, 1.0f / sz);
+                // the hardware reciprocal (1 ulp) is enough here: leaf boxes are widened by 4e-6 of their coordinates
+                // (tens of ulps) against rounding in the slab test, and the primitive tests, which decide the hit, do not
+                // use these values. A correctly rounded divide costs ten instructions a component.
+                id = V(__builtin_amdgcn_rcpf(sx), __builtin_amdgcn_rcpf(sy), __builtin_amdgcn_rcpf(sz));
                 nood = V(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
                 sp = 0;
                 node = sc.root;
