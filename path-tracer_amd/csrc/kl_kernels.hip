@@ -313,7 +313,10 @@ __global__ __launch_bounds__(256) void k_intersect_flat(SceneDev sc, FrameDev f,
 }
 
 // ------------------------------------------------------------------ intersect: BVH
-constexpr uint32_t ISECT_WAVES = 4;          // waves per workgroup
+#ifndef KL_ISECT_WAVES
+#define KL_ISECT_WAVES 4
+#endif
+constexpr uint32_t ISECT_WAVES = KL_ISECT_WAVES;          // waves per workgroup
 #ifndef KL_ISECT_CHUNK
 #define KL_ISECT_CHUNK 64          // small chunks: a wave that ends up with the last rays of a segment holds few of them
 #endif
