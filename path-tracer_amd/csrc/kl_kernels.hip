@@ -425,8 +425,9 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                 o = V(od.x, od.y, od.z); d = V(od.w, d2.x, d2.y);
                 h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
                 if (seeded) {
-                    float4 hr = hits[ray];
-                    h.t = hr.x; h.ref = __float_as_uint(hr.y); h.u = hr.z; h.v = hr.w;
+                    // distance and reference only: the record's (u, v) stay where they are unless a closer hit replaces the record
+                    const float2 hr = ((const float2 *)(hits + ray))[0];
+                    h.t = hr.x; h.ref = __float_as_uint(hr.y);
                     if (h.ref != REF_MISS) h.id = ID_UNKNOWN;           // fetched only if an exact tie asks for it
                 }
                 // slab reciprocals; a zero component is nudged so 0 * inf never appears
@@ -545,9 +546,13 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                         node = top;
                     } else {
                         // the address is formed here, from the ray index, rather than carried through the loop in two registers
-                        uint32_t slot = ray;
-                        asm volatile("" : "+v"(slot));
-                        hits[slot] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
+                        // A seeded ray that met nothing closer in the tree leaves its record as it is: h.id is still one of
+                        // the two values a seeded hit starts with (accept() stores a real id with every hit it takes).
+                        if (!(seeded && h.id >= ID_UNKNOWN)) {
+                            uint32_t slot = ray;
+                            asm volatile("" : "+v"(slot));
+                            hits[slot] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
+                        }
                         active = false;
                     }
                 }
