@@ -322,7 +322,7 @@ constexpr uint32_t ISECT_WAVES = KL_ISECT_WAVES;          // waves per workgroup
 #endif
 constexpr uint32_t ISECT_CHUNK = KL_ISECT_CHUNK;   // rays a wave takes from its segment's counter at a time
 #ifndef KL_ISECT_REFILL
-#define KL_ISECT_REFILL 48
+#define KL_ISECT_REFILL 52
 #endif
 #ifndef KL_ISECT_LDS_STACK
 #define KL_ISECT_LDS_STACK 10      // stack entries per lane kept in LDS; 10 + the staging area lets six workgroups share a CU
