@@ -1,7 +1,8 @@
 // GPU-side BVH builder: see kl_lbvh.hpp.
 //
 //   bounds     : padded box and area of every primitive, scene box (wave reduction + ordered-int atomics)
-//   keys       : 63-bit Morton code of the box centre; candidates for the flat list
+//   keys       : 63-bit Morton-style code of the box centre, each bit halving the currently longest cell axis;
+//                candidates for the flat list
 //   sort       : hipCUB radix sort of (code, primitive); flat primitives carry the largest key and end up last
 //   orders     : per-type leaf orders (exclusive scans of the type flags over the sorted sequence)
 //   hierarchy  : binary radix tree over the sorted codes (Karras 2012), ties broken by position
@@ -83,19 +84,29 @@ __global__ __launch_bounds__(256) void k_lbvh_bounds(const kl_sphere *s, uint32_
         }
 }
 
-// 21 bits -> every third bit of 63
-__device__ __forceinline__ unsigned long long spread3(uint32_t v) {
-    unsigned long long x = v & 0x1FFFFFull;
-    x = (x | x << 32) & 0x1F00000000FFFFull;
-    x = (x | x << 16) & 0x1F0000FF0000FFull;
-    x = (x | x << 8) & 0x100F00F00F00F00Full;
-    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
-    x = (x | x << 2) & 0x1249249249249249ull;
-    return x;
+// Which axis each of the 63 code bits halves, most significant first: always the axis along which the cell is
+// longest at that point, so that cells stay close to cubes whatever the proportions of the scene box (plain
+// interleaving gives a 1 : 1 : 4 room cells four times as long as wide at every level). axes[0..62] = axis of
+// bit, axes[64..66] = bits each axis gets.
+__global__ void k_lbvh_axes(const uint32_t *scene, uint8_t *axes) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float ext[3]; uint32_t nb[3] = { 0, 0, 0 };
+    for (int k = 0; k < 3; k++) { ext[k] = ord2f(scene[3 + k]) - ord2f(scene[k]); if (!(ext[k] > 0.0f)) ext[k] = 0.0f; }
+    for (int b = 0; b < 63; b++) {
+        int a = 0;
+        if (ext[1] > ext[a]) a = 1;
+        if (ext[2] > ext[a]) a = 2;
+        if (nb[a] >= 30u) {                       // an axis holds at most 30 bits: the next longest takes over
+            int o1 = (a + 1) % 3, o2 = (a + 2) % 3;
+            a = (nb[o1] < 30u && (ext[o1] >= ext[o2] || nb[o2] >= 30u)) ? o1 : o2;
+        }
+        axes[b] = (uint8_t)a; nb[a]++; ext[a] *= 0.5f;
+    }
+    for (int k = 0; k < 3; k++) axes[64 + k] = (uint8_t)nb[k];
 }
 
-__global__ __launch_bounds__(256) void k_lbvh_keys(const float4 *blo, const float4 *bhi, uint32_t n, const uint32_t *scene, float flat_fraction,
-                                                   FlatCand *cand, uint32_t *ncand, unsigned long long *keys, uint32_t *vals) {
+__global__ __launch_bounds__(256) void k_lbvh_keys(const float4 *blo, const float4 *bhi, uint32_t n, const uint32_t *scene, const uint8_t *axes,
+                                                   float flat_fraction, FlatCand *cand, uint32_t *ncand, unsigned long long *keys, uint32_t *vals) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
     float slo[3], ext[3];
@@ -107,14 +118,26 @@ __global__ __launch_bounds__(256) void k_lbvh_keys(const float4 *blo, const floa
         if (idx < FLAT_CAP) { cand[idx].prim = g; cand[idx].area = lo.w; }
     }
     const float c[3] = { 0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z) };
-    uint32_t ic[3];
+    // the box centre on a grid of 2^nb cells per axis, then the bits dealt out in the order k_lbvh_axes chose
+    uint32_t ic[3], left[3];
     for (int k = 0; k < 3; k++) {
-        float u = ext[k] > 0.0f ? (c[k] - slo[k]) / ext[k] : 0.0f;
-        u = !(u >= 0.0f) ? 0.0f : (u > 1.0f ? 1.0f : u);
-        const uint32_t i = (uint32_t)(u * 2097152.0f);
-        ic[k] = i > 2097151u ? 2097151u : i;
+        const uint32_t nb = axes[64 + k];
+        double u = ext[k] > 0.0f ? ((double)c[k] - (double)slo[k]) / (double)ext[k] : 0.0;
+        u = !(u >= 0.0) ? 0.0 : (u > 1.0 ? 1.0 : u);
+        const double cells = (double)(1ull << nb);
+        double q = u * cells;
+        if (q > cells - 1.0) q = cells - 1.0;
+        ic[k] = (uint32_t)q; left[k] = nb;
     }
-    keys[g] = (spread3(ic[0]) << 2) | (spread3(ic[1]) << 1) | spread3(ic[2]);
+    unsigned long long key = 0ull;
+    for (int b = 0; b < 63; b++) {
+        const uint32_t a = axes[b];
+        const uint32_t v = a == 0u ? ic[0] : (a == 1u ? ic[1] : ic[2]);
+        const uint32_t l = (a == 0u ? left[0] : (a == 1u ? left[1] : left[2])) - 1u;
+        key = (key << 1) | (unsigned long long)((v >> l) & 1u);
+        if (a == 0u) left[0] = l; else if (a == 1u) left[1] = l; else left[2] = l;
+    }
+    keys[g] = key;
     vals[g] = g;
 }
 // flat primitives sort behind every Morton code (which has 63 bits)
@@ -217,9 +240,22 @@ __global__ __launch_bounds__(256) void k_lbvh_collapse(uint32_t begin, uint32_t 
     const uint32_t idx = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= end) return;
     const int b2 = src[idx];
-    CBox box[4]; int ref[4]; int nch = 2;
-    ref[0] = left[b2]; ref[1] = right[b2];
-    box[0] = child_box(ref[0], vals, blo, bhi, ilo, ihi); box[1] = child_box(ref[1], vals, blo, bhi, ilo, ihi);
+    // a child is an inner binary node (ref >= 0, may be opened) or a finished leaf reference (ref = -1, the reference
+    // itself in leaf[]). Two sibling leaves of one primitive type become ONE two-primitive leaf: they are neighbours
+    // in the sorted sequence, hence in their type's leaf order, and testing two primitives costs less than visiting a
+    // node whose only job is to tell them apart.
+    CBox box[4]; int ref[4]; int leaf[4]; int nch = 2;
+    auto child = [&](int c, int k) {
+        box[k] = child_box(c, vals, blo, bhi, ilo, ihi);
+        if (c < 0) { ref[k] = -1; leaf[k] = leafref[~c]; return; }
+        const int l = left[c], r = right[c];
+        if (l < 0 && r < 0) {
+            const uint32_t a = (uint32_t)~leafref[~l], b = (uint32_t)~leafref[~r];       // (type << 29) | ((count-1) << 26) | start
+            if ((a >> 29) == (b >> 29) && (b & 0x3FFFFFFu) == (a & 0x3FFFFFFu) + 1u) { ref[k] = -1; leaf[k] = ~(int)(a + (1u << 26)); return; }
+        }
+        ref[k] = c; leaf[k] = 0;
+    };
+    child(left[b2], 0); child(right[b2], 1);
     while (nch < 4) {                      // open the inner child with the largest box
         int best = -1; float best_area = -1.0f;
         for (int k = 0; k < nch; k++) {
@@ -228,8 +264,8 @@ __global__ __launch_bounds__(256) void k_lbvh_collapse(uint32_t begin, uint32_t 
         }
         if (best < 0) break;
         const int open = ref[best];
-        ref[best] = left[open]; box[best] = child_box(ref[best], vals, blo, bhi, ilo, ihi);
-        ref[nch] = right[open]; box[nch] = child_box(ref[nch], vals, blo, bhi, ilo, ihi);
+        child(left[open], best);
+        child(right[open], nch);
         nch++;
     }
     float nlo[3], nhi[3];
@@ -265,7 +301,7 @@ __global__ __launch_bounds__(256) void k_lbvh_collapse(uint32_t begin, uint32_t 
     uint32_t next = n_inner ? atomicAdd(alloc, n_inner) : 0u;
     for (int k = 0; k < nch; k++) {
         if (ref[k] >= 0) { src[next] = ref[k]; w[12 + k] = next++; }
-        else w[12 + k] = (uint32_t)leafref[~ref[k]];
+        else w[12 + k] = (uint32_t)leaf[k];
     }
     for (int k = nch; k < 4; k++) w[12 + k] = w[12];     // an empty slot repeats child 0: always a valid reference
     uint4 *dst = (uint4 *)(nodes4 + (size_t)idx * 16);
@@ -294,21 +330,22 @@ LbvhResult build_bvh_gpu(hipStream_t stream, const kl_sphere *s, uint32_t ns, co
     if (n == 0) return LBVH_OK;
     hipError_t e = hipSuccess;
 #define LB(call) do { e = (call); if (e != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e); return LBVH_HIP_ERROR; } } while (0)
-    Buf d_s, d_q, d_t, d_blo, d_bhi, d_scene, d_cand, d_ncand, d_keys[2], d_vals[2], d_tmp, d_flat;
+    Buf d_s, d_q, d_t, d_blo, d_bhi, d_scene, d_axes, d_cand, d_ncand, d_keys[2], d_vals[2], d_tmp, d_flat;
     LB(d_s.alloc((size_t)ns * sizeof(kl_sphere))); LB(d_q.alloc((size_t)nq * sizeof(kl_quad))); LB(d_t.alloc((size_t)nt * sizeof(kl_tri)));
     if (ns) LB(hipMemcpyAsync(d_s.p, s, (size_t)ns * sizeof(kl_sphere), hipMemcpyHostToDevice, stream));
     if (nq) LB(hipMemcpyAsync(d_q.p, q, (size_t)nq * sizeof(kl_quad), hipMemcpyHostToDevice, stream));
     if (nt) LB(hipMemcpyAsync(d_t.p, t, (size_t)nt * sizeof(kl_tri), hipMemcpyHostToDevice, stream));
     LB(d_blo.alloc((size_t)n * 16)); LB(d_bhi.alloc((size_t)n * 16));
-    LB(d_scene.alloc(6 * 4)); LB(d_cand.alloc(FLAT_CAP * sizeof(FlatCand))); LB(d_ncand.alloc(4));
+    LB(d_scene.alloc(6 * 4)); LB(d_axes.alloc(128)); LB(d_cand.alloc(FLAT_CAP * sizeof(FlatCand))); LB(d_ncand.alloc(4));
     for (int k = 0; k < 2; k++) { LB(d_keys[k].alloc((size_t)n * 8)); LB(d_vals[k].alloc((size_t)n * 4)); }
     const uint32_t scene0[6] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u };
     LB(hipMemcpyAsync(d_scene.p, scene0, sizeof scene0, hipMemcpyHostToDevice, stream));
     LB(hipMemsetAsync(d_ncand.p, 0, 4, stream));
     hipLaunchKernelGGL(k_lbvh_bounds, dim3(blocks_for(n)), dim3(256), 0, stream, d_s.as<kl_sphere>(), ns, d_q.as<kl_quad>(), nq, d_t.as<kl_tri>(), nt,
                        d_blo.as<float4>(), d_bhi.as<float4>(), d_scene.as<uint32_t>());
+    hipLaunchKernelGGL(k_lbvh_axes, dim3(1), dim3(64), 0, stream, d_scene.as<uint32_t>(), d_axes.as<uint8_t>());
     hipLaunchKernelGGL(k_lbvh_keys, dim3(blocks_for(n)), dim3(256), 0, stream, d_blo.as<float4>(), d_bhi.as<float4>(), n, d_scene.as<uint32_t>(),
-                       max_flat ? flat_fraction : 0.0f, d_cand.as<FlatCand>(), d_ncand.as<uint32_t>(), d_keys[0].as<unsigned long long>(), d_vals[0].as<uint32_t>());
+                       d_axes.as<uint8_t>(), max_flat ? flat_fraction : 0.0f, d_cand.as<FlatCand>(), d_ncand.as<uint32_t>(), d_keys[0].as<unsigned long long>(), d_vals[0].as<uint32_t>());
     // which candidates are flat: all of them, the max_flat largest, or (more candidates than the list holds) none
     uint32_t ncand = 0;
     LB(hipMemcpyAsync(&ncand, d_ncand.p, 4, hipMemcpyDeviceToHost, stream));
@@ -406,7 +443,7 @@ LbvhResult build_bvh_gpu(hipStream_t stream, const kl_sphere *s, uint32_t ns, co
     for (uint32_t g : flat) fc[g < ns ? PRIM_SPHERE : (g < ns + nq ? PRIM_QUAD : PRIM_TRI)]++;
     const uint32_t cnt[3] = { ns, nq, nt };
     for (int k = 0; k < 3; k++) { out.flat_count[k] = fc[k]; out.flat_start[k] = cnt[k] - fc[k]; }
-    out.stats.nodes = count4; out.stats.leaves = n_tree; out.stats.max_depth = depth4; out.stats.max_leaf_size = n_tree ? 1u : 0u;
+    out.stats.nodes = count4; out.stats.leaves = n_tree; out.stats.max_depth = depth4; out.stats.max_leaf_size = n_tree ? (n_tree > 2 ? 2u : 1u) : 0u;
     out.stats.sah_cost = 0.0f;
     out.stats.node_bytes = (uint64_t)count4 * 64u;
     out.stats.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -14,7 +14,7 @@ namespace kl {
 
 enum LbvhResult { LBVH_OK = 0, LBVH_TOO_DEEP = 1, LBVH_HIP_ERROR = -1 };
 
-// Builds on `stream`'s device. Every leaf holds one primitive. LBVH_TOO_DEEP: the tree is deeper than the
+// Builds on `stream`'s device. A leaf holds one primitive, or two that were siblings in the binary tree. LBVH_TOO_DEEP: the tree is deeper than the
 // traversal stack allows (BVH_MAX_DEPTH 4-wide levels; possible when very many primitives share a Morton
 // cell) and the caller builds on the host instead; LBVH_HIP_ERROR: a HIP call failed (`err` says which).
 // Primitives whose box area is at least `flat_fraction` of the scene's (at most `max_flat`, and at most

@@ -127,7 +127,7 @@ def test_gpu_built_tree_finds_the_same_hits():
         r.update_params(bvh_builder=kl.BUILD_GPU_LBVH)
         r.upload_scene(s, q, t, m)
         st = r.bvh_stats()
-        assert st.builder == kl.BUILD_GPU_LBVH and st.max_leaf_size == 1
+        assert st.builder == kl.BUILD_GPU_LBVH and st.max_leaf_size <= 2
         assert (st.spheres, st.quads, st.tris) == (len(s), len(q), len(t))
         assert st.flat_quads == 7 and st.leaves == len(s) + len(q) + len(t) - 7       # the room's walls stay out of the tree
         assert 1 <= st.nodes <= st.leaves - 1 and st.max_depth <= 32 and st.node_bytes == st.nodes * 64
