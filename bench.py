@@ -26,7 +26,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 VALU_PEAK_TFLOPS = 157.3       # MI355X vector fp32 peak (packed multiply-add on every lane of 256 CUs at 2.4 GHz)
-QUEUE_BYTES_PER_RAY = 112      # write+read of the 40-byte ray plus write+read of the 16-byte hit
+QUEUE_BYTES_PER_RAY = 112      # per ray and bounce: the queue entry (ray, hit, throughput) written once and read twice, as first budgeted;
+                               # the current layout moves 48 B written + 32 B (traversal) + 48 B (shade) read + 8 B for one ray in five
 
 
 def load_textures():

@@ -50,17 +50,17 @@ template <typename T> struct DevBuf {
 constexpr uint32_t KL_MAX_BATCH_LANES = 4;
 struct BatchLane {
     hipStream_t stream = nullptr;
-    DevBuf<float4> d_od[2], d_tp[2], d_hits[2], d_raw;   // hit records ping-pong like the queues: shade reads one, writes the next bounce's flat hits into the other
-    DevBuf<float2> d_d2[2];
-    DevBuf<float4> p_od, p_hits;      // one-frame queue of the camera rays and their hits, shared by the frames of a batch
-    DevBuf<float2> p_d2;
+    DevBuf<float4> d_od[2], d_dt[2], d_tp[2], d_raw;     // the two ray queues (layout: RayQueue in kl_types.hpp) and the raw frames
+    DevBuf<float2> d_uv[2];
+    DevBuf<float4> p_od, p_dt;        // one-frame queue of the camera rays and their hits, shared by the frames of a batch
+    DevBuf<float2> p_uv;
     DevBuf<uint32_t> d_qctl;          // count[0..B], head[0..B]
     DevBuf<int> d_overflow;           // traversal stack entries beyond the LDS part
     hipEvent_t done = nullptr;        // recorded after the lane's latest accumulate
     void release() {
-        for (int k = 0; k < 2; k++) { d_od[k].release(); d_d2[k].release(); d_tp[k].release(); }
-        d_hits[0].release(); d_hits[1].release(); d_raw.release(); d_qctl.release(); d_overflow.release();
-        p_od.release(); p_hits.release(); p_d2.release();
+        for (int k = 0; k < 2; k++) { d_od[k].release(); d_dt[k].release(); d_tp[k].release(); d_uv[k].release(); }
+        d_raw.release(); d_qctl.release(); d_overflow.release();
+        p_od.release(); p_dt.release(); p_uv.release();
     }
 };
 
@@ -186,12 +186,11 @@ kl_status ensure_buffers(kl_ctx *c, uint32_t lanes = 1, uint32_t frames = 1) {
         }
         if (!L.done) KL_HIP(c, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
         for (int k = 0; k < 2; k++) {
-            KL_HIP(c, L.d_od[k].alloc(qcap)); KL_HIP(c, L.d_d2[k].alloc(qcap)); KL_HIP(c, L.d_tp[k].alloc(qcap));
+            KL_HIP(c, L.d_od[k].alloc(qcap)); KL_HIP(c, L.d_dt[k].alloc(qcap)); KL_HIP(c, L.d_tp[k].alloc(qcap)); KL_HIP(c, L.d_uv[k].alloc(qcap));
         }
-        KL_HIP(c, L.d_hits[0].alloc(qcap)); KL_HIP(c, L.d_hits[1].alloc(qcap));
         KL_HIP(c, L.d_raw.alloc(cap));
         KL_HIP(c, L.d_qctl.alloc(2 * ((size_t)c->params.max_bounces + 3) * KL_QUEUE_SEGMENTS * CTR_STRIDE));
-        KL_HIP(c, L.p_od.alloc(qcap1)); KL_HIP(c, L.p_d2.alloc(qcap1)); KL_HIP(c, L.p_hits.alloc(qcap1));
+        KL_HIP(c, L.p_od.alloc(qcap1)); KL_HIP(c, L.p_dt.alloc(qcap1)); KL_HIP(c, L.p_uv.alloc(qcap1));
         KL_HIP(c, L.d_overflow.alloc(intersect_overflow_ints(c->lc)));
     }
     c->n_lanes = std::max(c->n_lanes, lanes);
@@ -263,19 +262,19 @@ bool use_bvh(const kl_ctx *c) {
 }
 
 // `flat_done`: the kernel that produced the rays has already written their flat-primitive hit records
-kl_status timed_intersect(kl_ctx *c, BatchLane &L, const FrameDev &f, RayQueue q, float4 *hits, uint32_t *count, uint32_t *head, uint32_t max_rays,
+kl_status timed_intersect(kl_ctx *c, BatchLane &L, const FrameDev &f, RayQueue q, uint32_t *count, uint32_t *head, uint32_t max_rays,
                           bool flat_done) {
     hipEvent_t a = nullptr, b = nullptr;
     const bool bvh = use_bvh(c);
     if (bvh && scene_has_flat(c->sc) && !flat_done)
-        launch_intersect_flat(L.stream, c->lc, c->sc, f, q, hits, count, c->d_counters.p, c->params.collect_stats != 0, max_rays);
+        launch_intersect_flat(L.stream, c->lc, c->sc, f, q, count, c->d_counters.p, c->params.collect_stats != 0, max_rays);
     // the events bracket the dominant kernel only (k_intersect_bvh, or the flat loop for small scenes)
     if (c->params.profile_kernels) {
         if (c->pending.size() >= KL_MAX_PENDING_EVENTS) drain_events(c);
         a = get_event(c); b = get_event(c);
         if (a && b) KL_HIP(c, hipEventRecord(a, L.stream));
     }
-    launch_intersect(L.stream, c->lc, c->sc, f, q, hits, count, head, c->d_counters.p, L.d_overflow.p, bvh,
+    launch_intersect(L.stream, c->lc, c->sc, f, q, count, head, c->d_counters.p, L.d_overflow.p, bvh,
                      c->params.collect_stats != 0, max_rays, flat_done);
     if (a && b) { KL_HIP(c, hipEventRecord(b, L.stream)); c->pending.push_back({a, b, 0}); }
     return KL_OK;
@@ -290,7 +289,7 @@ kl_status render_batch(kl_ctx *c, BatchLane &L, hipEvent_t after, uint32_t first
     const size_t S = (size_t)KL_QUEUE_SEGMENTS * CTR_STRIDE;      // words per bounce level
     uint32_t *count = L.d_qctl.p, *head = L.d_qctl.p + (size_t)(B + 3) * S;
     const uint32_t max_rays = nslots * c->npl;
-    RayQueue q[2] = { {L.d_od[0].p, L.d_d2[0].p, L.d_tp[0].p}, {L.d_od[1].p, L.d_d2[1].p, L.d_tp[1].p} };
+    RayQueue q[2] = { {L.d_od[0].p, L.d_dt[0].p, L.d_tp[0].p, L.d_uv[0].p}, {L.d_od[1].p, L.d_dt[1].p, L.d_tp[1].p, L.d_uv[1].p} };
     const bool fused = c->params.fused_compaction != 0;
     const uint32_t levels = c->mode == KL_MODE_PT ? B : (c->mode == KL_MODE_AO ? 2u : 1u);
     KL_HIP(c, hipMemsetAsync(count, 0, (size_t)(levels + 1) * S * sizeof(uint32_t), L.stream));
@@ -299,32 +298,30 @@ kl_status render_batch(kl_ctx *c, BatchLane &L, hipEvent_t after, uint32_t first
     // once (a one-frame queue of its own) and generate copies its hit to the paths of all frames.
     const bool shared = nslots > 1 && c->params.trace_primary_per_frame == 0;
     // The flat primitives (scene-spanning ones kept out of the tree) are tested by the kernel that makes a ray, generate
-    // or shade, while the ray is in registers; only the stand-alone compaction moves rays afterwards and needs the
-    // separate flat pass. Hit records ping-pong with the queues: shade reads hits[b & 1] and writes the other.
+    // or shade, while the ray is in registers, and the hit travels in the ray's queue entry; only the stand-alone
+    // compaction moves rays afterwards and needs the separate flat pass.
     const bool pflat = use_bvh(c) && scene_has_flat(c->sc) && fused && !c->flat_separate;
-    float4 *hits[2] = { L.d_hits[0].p, L.d_hits[1].p };
     if (shared) {
         FrameDev f1 = f; f1.nslots = 1; f1.segcap = c->segcap1;
         uint32_t *count1 = count + (size_t)(B + 2) * S, *head1 = head + (size_t)(B + 2) * S;
         KL_HIP(c, hipMemsetAsync(count1, 0, S * sizeof(uint32_t), L.stream));
         KL_HIP(c, hipMemsetAsync(head1, 0, S * sizeof(uint32_t), L.stream));
-        RayQueue q1 = { L.p_od.p, L.p_d2.p, nullptr };
-        launch_generate(L.stream, c->lc, c->sc, f1, q1, count1, nullptr, 0, L.p_hits.p, pflat);
-        kl_status s1 = timed_intersect(c, L, f1, q1, L.p_hits.p, count1, head1, c->npl, pflat);
+        RayQueue q1 = { L.p_od.p, L.p_dt.p, nullptr, L.p_uv.p };
+        launch_generate(L.stream, c->lc, c->sc, f1, q1, count1, pflat);
+        kl_status s1 = timed_intersect(c, L, f1, q1, count1, head1, c->npl, pflat);
         if (s1 != KL_OK) return s1;
-        launch_generate(L.stream, c->lc, c->sc, f, q[0], count, L.p_hits.p, c->segcap1, hits[0]);
+        launch_generate(L.stream, c->lc, c->sc, f, q[0], count, false, q1, c->segcap1);
     } else {
-        launch_generate(L.stream, c->lc, c->sc, f, q[0], count, nullptr, 0, hits[0], pflat);
+        launch_generate(L.stream, c->lc, c->sc, f, q[0], count, pflat);
     }
     for (uint32_t b = 0; b < levels; b++) {
         RayQueue qi = q[b & 1u], qo = q[(b + 1u) & 1u];
-        float4 *hi = pflat ? hits[b & 1u] : hits[0];
         if (!(shared && b == 0)) {
-            kl_status s = timed_intersect(c, L, f, qi, hi, count + (size_t)b * S, head + (size_t)b * S, max_rays, pflat);
+            kl_status s = timed_intersect(c, L, f, qi, count + (size_t)b * S, head + (size_t)b * S, max_rays, pflat);
             if (s != KL_OK) return s;
         }
-        launch_shade(L.stream, c->lc, c->sc, f, qi, hi, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, L.d_raw.p, b, fused, max_rays,
-                     pflat && b + 1 < levels ? hits[(b + 1u) & 1u] : nullptr);
+        launch_shade(L.stream, c->lc, c->sc, f, qi, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, L.d_raw.p, b, fused, max_rays,
+                     pflat && b + 1 < levels);
         if (!fused && b + 1 < levels) launch_compact(L.stream, c->lc, f, qi, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, max_rays);
     }
     if (after) KL_HIP(c, hipStreamWaitEvent(L.stream, after, 0));
@@ -605,7 +602,7 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
             r[0] = make_float4(x.v0[0], x.v0[1], x.v0[2], x.v1[0]);
             r[1] = make_float4(x.v1[1], x.v1[2], x.v2[0], x.v2[1]);
             r[2] = make_float4(x.v2[2], x.v3[0], x.v3[1], x.v3[2]);
-            r[3] = make_float4(bits(ns + bvh.quad_order[k]), bits(x.material), 0.0f, 0.0f);
+            r[3] = make_float4(bits(ns + bvh.quad_order[k]), bits(x.material), bits(m[x.material].type == KL_TEXTURED ? 1u : 0u), 0.0f);
             v3 v1 = V(x.v1[0], x.v1[1], x.v1[2]), v2 = V(x.v2[0], x.v2[1], x.v2[2]), v3_ = V(x.v3[0], x.v3[1], x.v3[2]);
             shade_rec((size_t)ns + k, normalize(cross(v2 - v1, v3_ - v1)), m[x.material], make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0));   // RawFrame.glsl:319
         }
@@ -619,7 +616,7 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
             float4 *r = &rec[4 * ((size_t)base[PRIM_TRI] + k)];
             r[0] = make_float4(v0.x, v0.y, v0.z, e1.x);
             r[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-            r[2] = make_float4(e2.z, bits(ns + nq + bvh.tri_order[k]), bits(x.material), 0.0f);
+            r[2] = make_float4(e2.z, bits(ns + nq + bvh.tri_order[k]), bits(x.material), bits(m[x.material].type == KL_TEXTURED ? 1u : 0u));
             r[3] = zero4;
             shade_rec((size_t)ns + nq + k, nor, m[x.material], make_float4(0, 0, x.uv0[0], x.uv0[1]), make_float4(x.uv1[0], x.uv1[1], x.uv2[0], x.uv2[1]));
         }
@@ -644,7 +641,7 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
         flatq[5 * (size_t)k + 1] = make_float4(nor.x, nor.y, nor.z, k2);
         flatq[5 * (size_t)k + 2] = make_float4(kax, kay, kbx, kby);
         flatq[5 * (size_t)k + 3] = make_float4(kgx, kgy, bits((uint32_t)idu | ((uint32_t)idv << 2)), 0.0f);
-        flatq[5 * (size_t)k + 4] = make_float4(bits(ns + qi), 0.0f, 0.0f, 0.0f);
+        flatq[5 * (size_t)k + 4] = make_float4(bits(ns + qi), bits(m[x.material].type == KL_TEXTURED ? 1u : 0u), 0.0f, 0.0f);
     }
     kl_status st;
     if ((st = upload(c, c->d_flatq, flatq.data(), flatq.size())) != KL_OK) return st;
@@ -819,31 +816,36 @@ kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, f
     if (n == 0) return KL_OK;
     if (n > (1u << 28)) return fail(c, KL_E_LIMIT, "at most 2^28 rays per call");
     KL_HIP(c, hipSetDevice(c->device));
-    std::vector<float4> od(n); std::vector<float2> d2(n);
+    // the caller's rays as one queue segment; every entry starts as a miss
+    const float miss_t = c->params.max_dist;
+    float miss_ref; { const uint32_t r = REF_MISS; std::memcpy(&miss_ref, &r, 4); }
+    std::vector<float4> od(n), dt(n);
     for (uint32_t i = 0; i < n; i++) {
         od[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i]);
-        d2[i] = make_float2(d[3 * i + 1], d[3 * i + 2]);
+        dt[i] = make_float4(d[3 * i + 1], d[3 * i + 2], miss_t, miss_ref);
     }
-    DevBuf<float4> b_od, b_hits; DevBuf<float2> b_d2, b_uv; DevBuf<float> b_t; DevBuf<uint32_t> b_prim, b_ctl;
+    DevBuf<float4> b_od, b_dt; DevBuf<float2> b_quv, b_uv; DevBuf<float> b_t; DevBuf<uint32_t> b_prim, b_ctl;
     struct Cleanup { DevBuf<float4> &a, &b; DevBuf<float2> &c, &d; DevBuf<float> &e; DevBuf<uint32_t> &f, &g;
                      ~Cleanup() { a.release(); b.release(); c.release(); d.release(); e.release(); f.release(); g.release(); } }
-        cleanup{b_od, b_hits, b_d2, b_uv, b_t, b_prim, b_ctl};
-    KL_HIP(c, b_od.alloc(n)); KL_HIP(c, b_hits.alloc(n)); KL_HIP(c, b_d2.alloc(n)); KL_HIP(c, b_uv.alloc(n));
+        cleanup{b_od, b_dt, b_quv, b_uv, b_t, b_prim, b_ctl};
+    KL_HIP(c, b_od.alloc(n)); KL_HIP(c, b_dt.alloc(n)); KL_HIP(c, b_quv.alloc(n)); KL_HIP(c, b_uv.alloc(n));
     KL_HIP(c, b_t.alloc(n)); KL_HIP(c, b_prim.alloc(n)); KL_HIP(c, b_ctl.alloc(2));   // one segment: count, head
     if (!c->d_counters.p) { KL_HIP(c, c->d_counters.alloc(1)); KL_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream)); }
     KL_HIP(c, c->lanes[0].d_overflow.alloc(intersect_overflow_ints(c->lc)));
     const uint32_t ctl[2] = { n, 0 };
     KL_HIP(c, hipMemcpyAsync(b_od.p, od.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    KL_HIP(c, hipMemcpyAsync(b_d2.p, d2.data(), n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    KL_HIP(c, hipMemcpyAsync(b_dt.p, dt.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    KL_HIP(c, hipMemsetAsync(b_quv.p, 0, n * sizeof(float2), c->stream));
     KL_HIP(c, hipMemcpyAsync(b_ctl.p, ctl, sizeof ctl, hipMemcpyHostToDevice, c->stream));
     FrameDev f = make_frame(c, 0, 1);
     f.nseg = 1; f.segcap = n;                       // caller rays form one segment
-    RayQueue q = { b_od.p, b_d2.p, nullptr };
+    f.all_uv = 1;                                   // (u, v) of every hit, whatever its material
+    RayQueue q = { b_od.p, b_dt.p, nullptr, b_quv.p };
     if (use_bvh(c) && scene_has_flat(c->sc))
-        launch_intersect_flat(c->stream, c->lc, c->sc, f, q, b_hits.p, &b_ctl.p[0], c->d_counters.p, c->params.collect_stats != 0, n);
-    launch_intersect(c->stream, c->lc, c->sc, f, q, b_hits.p, &b_ctl.p[0], &b_ctl.p[1], c->d_counters.p, c->lanes[0].d_overflow.p, use_bvh(c),
+        launch_intersect_flat(c->stream, c->lc, c->sc, f, q, &b_ctl.p[0], c->d_counters.p, c->params.collect_stats != 0, n);
+    launch_intersect(c->stream, c->lc, c->sc, f, q, &b_ctl.p[0], &b_ctl.p[1], c->d_counters.p, c->lanes[0].d_overflow.p, use_bvh(c),
                      c->params.collect_stats != 0, n);
-    launch_unpack_hits(c->stream, c->sc, b_hits.p, n, b_t.p, b_prim.p, b_uv.p);
+    launch_unpack_hits(c->stream, c->sc, q, n, b_t.p, b_prim.p, b_uv.p);
     KL_HIP(c, hipMemcpyAsync(t, b_t.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     KL_HIP(c, hipMemcpyAsync(prim, b_prim.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     KL_HIP(c, hipMemcpyAsync(uv, b_uv.p, n * sizeof(float2), hipMemcpyDeviceToHost, c->stream));

@@ -110,7 +110,7 @@ __device__ __forceinline__ bool tri_intersect(v3 o, v3 d, v3 v0, v3 e1, v3 e2, f
     return true;
 }
 
-struct Hit { float t; uint32_t ref; float u, v; uint32_t id; };
+struct Hit { float t; uint32_t ref; float u, v; uint32_t id; uint32_t uvf; };   // uvf: the primitive's uv flag (shading reads u, v)
 
 // declaration-order id of a primitive reference (read from its record)
 __device__ __forceinline__ uint32_t ref_id(const SceneDev &sc, uint32_t ref) {
@@ -124,31 +124,31 @@ constexpr uint32_t ID_UNKNOWN = 0xFFFFFFFEu;
 // acceptance rule of RF:302,316 (`t < best && t > 0.001`); on exactly equal t the lower
 // declaration-order id wins, which is what the shader's in-order loop with a strict `<` does.
 // `lazy`: h.id may be ID_UNKNOWN (h came from a hit record, which has no room for the id).
-__device__ __forceinline__ void accept(Hit &h, float t, uint32_t ref, uint32_t id, float u, float v, const SceneDev *lazy = nullptr) {
+__device__ __forceinline__ void accept(Hit &h, float t, uint32_t ref, uint32_t id, float u, float v, uint32_t uvf, const SceneDev *lazy = nullptr) {
     if (!(t > 0.001f)) return;
     bool take = t < h.t;
     if (t == h.t) {
         if (lazy && h.id == ID_UNKNOWN) h.id = ref_id(*lazy, h.ref);
         take = id < h.id;
     }
-    if (take) { h.t = t; h.ref = ref; h.id = id; h.u = u; h.v = v; }
+    if (take) { h.t = t; h.ref = ref; h.id = id; h.u = u; h.v = v; h.uvf = uvf; }
 }
 // primitive tests on the 64-byte records of kl_types.hpp
 __device__ __forceinline__ void test_sphere(float4 r0, float4 r1, uint32_t i, v3 o, v3 d, float eps, Hit &h, const SceneDev *lazy = nullptr) {
     float t;
-    if (sphere_intersect(o, d, r0, eps, t)) accept(h, t, make_ref(PRIM_SPHERE, i), __float_as_uint(r1.x), 0.0f, 0.0f, lazy);
+    if (sphere_intersect(o, d, r0, eps, t)) accept(h, t, make_ref(PRIM_SPHERE, i), __float_as_uint(r1.x), 0.0f, 0.0f, 0u, lazy);
 }
 __device__ __forceinline__ void test_quad(float4 a, float4 b, float4 c, float4 e, uint32_t i, v3 o, v3 d, Hit &h, const SceneDev *lazy = nullptr) {
     // the plane distance is the first thing RF:225 computes; a candidate that cannot pass the
     // acceptance test of RF:316 is dropped before the inverse-bilinear solve (same outcome)
     float t, u, v;
     if (quad_intersect(o, d, V(a.x, a.y, a.z), V(a.w, b.x, b.y), V(b.z, b.w, c.x), V(c.y, c.z, c.w), h.t, t, u, v))
-        accept(h, t, make_ref(PRIM_QUAD, i), __float_as_uint(e.x), u, v, lazy);
+        accept(h, t, make_ref(PRIM_QUAD, i), __float_as_uint(e.x), u, v, __float_as_uint(e.z), lazy);
 }
 __device__ __forceinline__ void test_tri(float4 a, float4 b, float4 c, uint32_t i, v3 o, v3 d, Hit &h, const SceneDev *lazy = nullptr) {
     float t, u, v;
     if (tri_intersect(o, d, V(a.x, a.y, a.z), V(a.w, b.x, b.y), V(b.z, b.w, c.x), t, u, v))
-        accept(h, t, make_ref(PRIM_TRI, i), __float_as_uint(c.y), u, v, lazy);
+        accept(h, t, make_ref(PRIM_TRI, i), __float_as_uint(c.y), u, v, __float_as_uint(c.w), lazy);
 }
 // A 16-byte load from an address that is the same in every lane, through the constant address space: the
 // compiler then uses the scalar cache and scalar registers instead of 64 identical vector loads. Only for data
@@ -180,7 +180,8 @@ __device__ __forceinline__ void flat_quads(const SceneDev &sc, v3 o, v3 d, Hit &
     const uint32_t nq = sc.flat_count[PRIM_QUAD];
     for (uint32_t k = 0; k < nq; k++) {
         const float4 F0 = uload(sc.flatq + 5 * k), F1 = uload(sc.flatq + 5 * k + 1), F2 = uload(sc.flatq + 5 * k + 2), F3 = uload(sc.flatq + 5 * k + 3);
-        const uint32_t id = __float_as_uint(uload(sc.flatq + 5 * k + 4).x);
+        const float4 F4 = uload(sc.flatq + 5 * k + 4);
+        const uint32_t id = __float_as_uint(F4.x);
         const v3 p = o - V(F0.x, F0.y, F0.z), nor = V(F1.x, F1.y, F1.z);
         const float t = -dot(p, nor) / dot(d, nor);                  // RF:225
         if (t < 0.0f) continue;                                      // RF:226
@@ -206,31 +207,37 @@ __device__ __forceinline__ void flat_quads(const SceneDev &sc, v3 o, v3 d, Hit &
             u = (kpx - kax * v) / (kbx + kgx * v);
         }
         if (u < 0.0f || u > 1.0f || v < 0.0f || v > 1.0f) continue;
-        accept(h, t, make_ref(PRIM_QUAD, sc.flat_start[PRIM_QUAD] + k), id, v, 1.0f - u);
+        accept(h, t, make_ref(PRIM_QUAD, sc.flat_start[PRIM_QUAD] + k), id, v, 1.0f - u, __float_as_uint(F4.y));
     }
 }
 
-// closest hit among the flat primitives (the scene-spanning ones kept out of the tree) as a hit record; the
-// traversal kernel starts from it, so it begins with the ray already clipped by the walls
-__device__ __forceinline__ float4 flat_hit(const SceneDev &sc, const FrameDev &f, v3 o, v3 d) {
-    Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
+// closest hit among the flat primitives (the scene-spanning ones kept out of the tree); the traversal kernel
+// starts from it, so it begins with the ray already clipped by the walls
+__device__ __forceinline__ Hit flat_hit(const SceneDev &sc, const FrameDev &f, v3 o, v3 d) {
+    Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu; h.uvf = 0u;
     if (ray_finite(o, d)) {
         test_range(sc, PRIM_SPHERE, sc.flat_start[PRIM_SPHERE], sc.flat_count[PRIM_SPHERE], o, d, f.eps, h);
         flat_quads(sc, o, d, h);
         test_range(sc, PRIM_TRI, sc.flat_start[PRIM_TRI], sc.flat_count[PRIM_TRI], o, d, f.eps, h);
     }
-    return make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
+    return h;
+}
+// queue slot of path i when generate deals 64-path groups round-robin over the segments
+__device__ __forceinline__ uint32_t dealt_slot(uint32_t i, uint32_t nseg, uint32_t segcap) {
+    const uint32_t g = i >> 6;
+    return (g % nseg) * segcap + (g / nseg) * 64u + (i & 63u);
 }
 
 // ------------------------------------------------------------------ generate
-// RF:417-422 with the uv arithmetic of RF:428-429,436; one thread per (slot, pixel)
-// With `seed_hits`: every frame of a batch starts with the same camera ray per pixel (the shader adds no sub-pixel
-// jitter, RF:436 with SPP = 1), so the closest hit of that ray was found once, for a one-frame queue of segment
-// capacity `seed_segcap`, and is copied here into the hit record of each frame's path.
-// With `flat` (and no seed hits): the camera ray is tested against the flat primitives here, while it is still in
-// registers, and hits[] receives the record the traversal starts from.
-__global__ __launch_bounds__(256) void k_generate(SceneDev sc, FrameDev f, RayQueue q, uint32_t *count0, const float4 *seed_hits,
-                                                  uint32_t seed_segcap, float4 *hits, uint32_t flat) {
+// RF:417-422 with the uv arithmetic of RF:428-429,436; one thread per (slot, pixel). Every ray leaves with the
+// closest hit so far in its queue entry:
+//   seed.od != null: every frame of a batch starts with the same camera ray per pixel (the shader adds no sub-pixel
+//     jitter, RF:436 with SPP = 1), so that ray was traced once, in the one-frame queue `seed` of segment capacity
+//     `seed_segcap`, and its hit is copied into the entry of each frame's path;
+//   else flat != 0: the camera ray is tested against the flat primitives here, while it is in registers;
+//   else: a miss (an intersect kernel that looks at every primitive follows).
+__global__ __launch_bounds__(256) void k_generate(SceneDev sc, FrameDev f, RayQueue q, uint32_t *count0, RayQueue seed,
+                                                  uint32_t seed_segcap, uint32_t flat) {
     const uint32_t total = f.nslots * f.npl;
     const uint32_t groups = (total + 63u) >> 6;            // 64-path groups, dealt round-robin over the segments
     if (blockIdx.x == 0) {
@@ -255,49 +262,58 @@ __global__ __launch_bounds__(256) void k_generate(SceneDev sc, FrameDev f, RayQu
             uy = (uy - 0.5f * psy) + (0.0f / 1.0f) * psy;
         }
         v3 d = normalize(pc + pu * ux + pv * uy - pos);
-        const uint32_t g = i >> 6;
-        const uint32_t dst = (g % f.nseg) * f.segcap + (g / f.nseg) * 64u + (i & 63u);
-        q.od[dst] = make_float4(pos.x, pos.y, pos.z, d.x);
-        q.d2[dst] = make_float2(d.y, d.z);
-        if (q.tp) q.tp[dst] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(i));
-        if (seed_hits) {
-            const uint32_t g0 = li >> 6;         // where generate put this pixel's ray in the one-frame queue
-            hits[dst] = seed_hits[(g0 % f.nseg) * seed_segcap + (g0 / f.nseg) * 64u + (li & 63u)];
+        const uint32_t dst = dealt_slot(i, f.nseg, f.segcap);
+        float t = f.max_dist; uint32_t ref = REF_MISS;
+        if (seed.od) {
+            const uint32_t src = dealt_slot(li, f.nseg, seed_segcap);    // this pixel's ray in the one-frame queue
+            const float4 sdt = seed.dt[src];
+            t = sdt.z; ref = __float_as_uint(sdt.w);
+            q.uv[dst] = seed.uv[src];                                   // meaningful only for textured primitives; copied blindly
         } else if (flat) {
-            hits[dst] = flat_hit(sc, f, pos, d);
+            const Hit h = flat_hit(sc, f, pos, d);
+            t = h.t; ref = h.ref;
+            if (h.uvf) q.uv[dst] = make_float2(h.u, h.v);
         }
+        q.od[dst] = make_float4(pos.x, pos.y, pos.z, d.x);
+        q.dt[dst] = make_float4(d.y, d.z, t, __uint_as_float(ref));
+        if (q.tp) q.tp[dst] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(i));
     }
+}
+
+// the two words of a queue entry that hold the closest hit, and the (u, v) of hits whose shading reads them
+__device__ __forceinline__ void store_hit(const RayQueue &q, uint32_t i, const Hit &h) {
+    ((float2 *)(q.dt + i))[1] = make_float2(h.t, __uint_as_float(h.ref));
+    if (h.uvf) q.uv[i] = make_float2(h.u, h.v);
 }
 
 // ------------------------------------------------------------------ intersect: flat loop
 // RF:294-328 for scenes of a few primitives: every lane walks the same primitive list, so the
 // geometry comes through uniform (scalar) loads and nothing but the ray and hit touch memory.
-__global__ __launch_bounds__(256) void k_intersect_brute(SceneDev sc, FrameDev f, RayQueue q, float4 *hits,
-                                                         const uint32_t *counts, Counters *cn) {
+__global__ __launch_bounds__(256) void k_intersect_brute(SceneDev sc, FrameDev f, RayQueue q, const uint32_t *counts, Counters *cn) {
     // block b works on segment b % nseg together with the other blocks of that residue
     const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
     const uint32_t count = counts[seg * CTR_STRIDE];
     if (sub == 0 && threadIdx.x == 0 && count) atomicAdd(&cn->rays, (unsigned long long)count);
     for (uint32_t r = sub * blockDim.x + threadIdx.x; r < count; r += nsub * blockDim.x) {
         const uint32_t i = seg * f.segcap + r;
-        float4 od = q.od[i]; float2 d2 = q.d2[i];
-        v3 o = V(od.x, od.y, od.z), d = V(od.w, d2.x, d2.y);
-        Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
+        float4 od = q.od[i]; float4 dt = q.dt[i];
+        v3 o = V(od.x, od.y, od.z), d = V(od.w, dt.x, dt.y);
+        Hit h; h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu; h.uvf = 0u;
         if (ray_finite(o, d)) {
             test_range(sc, PRIM_SPHERE, sc.base[PRIM_SPHERE], sc.count[PRIM_SPHERE], o, d, f.eps, h);
             test_range(sc, PRIM_QUAD, sc.base[PRIM_QUAD], sc.count[PRIM_QUAD], o, d, f.eps, h);
             test_range(sc, PRIM_TRI, sc.base[PRIM_TRI], sc.count[PRIM_TRI], o, d, f.eps, h);
         }
-        hits[i] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
+        if (f.all_uv) h.uvf = 1u;
+        store_hit(q, i, h);
     }
 }
 
 // The flat primitives for every ray of a queue, in queue order (uniform loads, no divergence). Writes the hit
-// record that k_intersect_bvh then starts from. The render loop does not need it: generate and shade run
-// flat_hit themselves on the rays they produce; this kernel serves rays that come from elsewhere (caller
-// rays, the stand-alone compaction).
-__global__ __launch_bounds__(256) void k_intersect_flat(SceneDev sc, FrameDev f, RayQueue q, float4 *hits,
-                                                        const uint32_t *counts, Counters *cn, uint32_t stats) {
+// that k_intersect_bvh then starts from. The render loop does not need it: generate and shade run flat_hit
+// themselves on the rays they produce; this kernel serves rays that come from elsewhere (caller rays, the
+// stand-alone compaction).
+__global__ __launch_bounds__(256) void k_intersect_flat(SceneDev sc, FrameDev f, RayQueue q, const uint32_t *counts, Counters *cn, uint32_t stats) {
     const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
     const uint32_t count = counts[seg * CTR_STRIDE];
     if (stats && sub == 0 && threadIdx.x == 0 && count) {
@@ -307,8 +323,10 @@ __global__ __launch_bounds__(256) void k_intersect_flat(SceneDev sc, FrameDev f,
     }
     for (uint32_t r = sub * blockDim.x + threadIdx.x; r < count; r += nsub * blockDim.x) {
         const uint32_t i = seg * f.segcap + r;
-        float4 od = q.od[i]; float2 d2 = q.d2[i];
-        hits[i] = flat_hit(sc, f, V(od.x, od.y, od.z), V(od.w, d2.x, d2.y));
+        float4 od = q.od[i]; float4 dt = q.dt[i];
+        Hit h = flat_hit(sc, f, V(od.x, od.y, od.z), V(od.w, dt.x, dt.y));
+        if (f.all_uv) h.uvf = 1u;
+        store_hit(q, i, h);
     }
 }
 
@@ -329,8 +347,8 @@ constexpr uint32_t ISECT_CHUNK = KL_ISECT_CHUNK;   // rays a wave takes from its
 #endif
 constexpr uint32_t ISECT_REFILL = KL_ISECT_REFILL;   // refill idle lanes when fewer than this many are active
 
-// `seeded`: hits[] already holds the closest flat-primitive hit of every ray (1: k_intersect_flat ran;
-// 2: the kernel that produced the rays ran the flat tests).
+// Every ray arrives with its closest hit so far in its queue entry (the flat-primitive hit its producer or
+// k_intersect_flat found, or a miss) and starts from there.
 //
 // Record fetch. A lane needs the 64 bytes of "its" record every step. Fetched by the lane itself that is four
 // 16-byte loads whose 64 lanes touch 64 different lines each: the L1 tag pipeline (about one line per clock
@@ -364,7 +382,7 @@ __device__ __forceinline__ void coop_fetch_one(const float4 *base, uint32_t my_o
 #define KL_ISECT_MIN_WAVES 6       // waves per SIMD the register allocation must allow (<= 80 VGPRs)
 #endif
 template <bool STATS>
-__global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_intersect_bvh(SceneDev sc, FrameDev f, RayQueue q, float4 *hits, uint32_t seeded,
+__global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_intersect_bvh(SceneDev sc, FrameDev f, RayQueue q, uint32_t tally_flat,
                                                                    const uint32_t *counts, uint32_t *heads, Counters *cn, int *overflow) {
     __shared__ int stack[ISECT_WAVES][ISECT_LDS_STACK][64];
     __shared__ float4 stage[ISECT_WAVES][4][STAGE_REGION_F4];
@@ -379,7 +397,7 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
     const uint32_t seg_base = seg * f.segcap;
     if (blockIdx.x < f.nseg && threadIdx.x == 0 && count) {
         atomicAdd(&cn->rays, (unsigned long long)count);
-        if (STATS && seeded == 2u) {          // flat tests done by the kernel that produced the rays: tallied here
+        if (STATS && tally_flat) {            // flat tests done by the kernel that produced the rays: tallied here
             atomicAdd(&cn->sphere_tests, (unsigned long long)count * sc.flat_count[PRIM_SPHERE]);
             atomicAdd(&cn->quad_tests, (unsigned long long)count * sc.flat_count[PRIM_QUAD]);
             atomicAdd(&cn->tri_tests, (unsigned long long)count * sc.flat_count[PRIM_TRI]);
@@ -391,14 +409,14 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
     bool active = false;
     uint32_t ray = 0; int node = NODE_DONE; int sp = 0;
     v3 o = V(0, 0, 0), d = V(0, 0, 0), id = V(0, 0, 0), nood = V(0, 0, 0);
-    Hit h; h.t = 0; h.ref = REF_MISS; h.u = h.v = 0; h.id = 0xFFFFFFFFu;
+    Hit h; h.t = 0; h.ref = REF_MISS; h.u = h.v = 0; h.id = 0xFFFFFFFFu; h.uvf = 0u;
     unsigned long long s_nodes = 0, s_sph = 0, s_quad = 0, s_tri = 0, s_act = 0, s_tot = 0;
 
     for (;;) {
         // ---- refill idle lanes from the wave's reserved range
         unsigned long long idle = __ballot(!active);
         if (idle != 0ull && !(exhausted && cur == end)) {
-            float touch0 = 0.0f, touch1 = 0.0f, touch2 = 0.0f; bool touched = false;
+            float touch0 = 0.0f, touch1 = 0.0f; bool touched = false;
             if (cur == end) {
                 uint32_t base = 0u;
                 if (lane == 0) base = atomicAdd(head, ISECT_CHUNK);
@@ -410,8 +428,7 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                     // wait for both): the chunk's later refills then find their rays in L2 instead of HBM
                     const uint32_t tr = seg_base + min(base + lane, count - 1u);
                     touch0 = ((const float *)(q.od + tr))[0];
-                    touch1 = ((const float *)(q.d2 + tr))[0];
-                    if (seeded) touch2 = ((const float *)(hits + tr))[0];
+                    touch1 = ((const float *)(q.dt + tr))[0];
                     touched = true;
                 }
             }
@@ -421,15 +438,12 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
             uint32_t r = mask_rank(idle);
             if (!active && r < take) {
                 ray = seg_base + cur + r;
-                float4 od = q.od[ray]; float2 d2 = q.d2[ray];
-                o = V(od.x, od.y, od.z); d = V(od.w, d2.x, d2.y);
-                h.t = f.max_dist; h.ref = REF_MISS; h.u = 0.0f; h.v = 0.0f; h.id = 0xFFFFFFFFu;
-                if (seeded) {
-                    // distance and reference only: the record's (u, v) stay where they are unless a closer hit replaces the record
-                    const float2 hr = ((const float2 *)(hits + ray))[0];
-                    h.t = hr.x; h.ref = __float_as_uint(hr.y);
-                    if (h.ref != REF_MISS) h.id = ID_UNKNOWN;           // fetched only if an exact tie asks for it
-                }
+                float4 od = q.od[ray]; float4 dt = q.dt[ray];
+                o = V(od.x, od.y, od.z); d = V(od.w, dt.x, dt.y);
+                // the entry's closest hit so far (its producer's flat-primitive hit, or a miss) is where the ray starts from;
+                // that hit's id is fetched only if an exact tie asks for it
+                h.t = dt.z; h.ref = __float_as_uint(dt.w); h.u = 0.0f; h.v = 0.0f; h.uvf = 0u;
+                h.id = h.ref != REF_MISS ? ID_UNKNOWN : 0xFFFFFFFFu;
                 // slab reciprocals; a zero component is nudged so 0 * inf never appears
                 float sx = fabsf(d.x) > 1e-20f ? d.x : copysignf(1e-20f, d.x);
                 float sy = fabsf(d.y) > 1e-20f ? d.y : copysignf(1e-20f, d.y);
@@ -442,13 +456,10 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                 sp = 0;
                 node = sc.root;
                 active = true;
-                if (node == NODE_DONE || !ray_finite(o, d)) {    // empty tree, or a NaN ray (hits nothing)
-                    if (!seeded) hits[ray] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);      // a miss
-                    active = false;
-                }
+                if (node == NODE_DONE || !ray_finite(o, d)) active = false;    // empty tree, or a NaN ray (hits nothing): the entry stands
             }
             cur += take;
-            if (touched) asm volatile("" :: "v"(touch0), "v"(touch1), "v"(touch2));   // keeps the requests; their values are not used
+            if (touched) asm volatile("" :: "v"(touch0), "v"(touch1));   // keeps the requests; their values are not used
         }
         unsigned long long am = __ballot(active);
         if (am == 0ull) { if (exhausted && cur == end) break; else continue; }
@@ -545,13 +556,14 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                         sp--;
                         node = top;
                     } else {
-                        // the address is formed here, from the ray index, rather than carried through the loop in two registers
-                        // A seeded ray that met nothing closer in the tree leaves its record as it is: h.id is still one of
-                        // the two values a seeded hit starts with (accept() stores a real id with every hit it takes).
-                        if (!(seeded && h.id >= ID_UNKNOWN)) {
+                        // A ray that met nothing closer in the tree leaves its entry as it is: h.id is still one of the two
+                        // values it started with (accept() stores a real id with every hit it takes). The address is
+                        // formed here, from the ray index, rather than carried through the loop in two registers.
+                        if (h.id < ID_UNKNOWN) {
                             uint32_t slot = ray;
                             asm volatile("" : "+v"(slot));
-                            hits[slot] = make_float4(h.t, __uint_as_float(h.ref), h.u, h.v);
+                            if (f.all_uv) h.uvf = 1u;
+                            store_hit(q, slot, h);
                         }
                         active = false;
                     }
@@ -576,11 +588,11 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
 }
 
 // ------------------------------------------------------------------ shading helpers
-struct Surf { v3 pos, n; bool inside; float u, v; };
+struct Surf { v3 pos, n; bool inside; };
 
 // the fields of the shader's Hit struct (RF:142-150) that shading reads, rebuilt from (ray, t, ref) and the
 // first words of the primitive's shading record: s0.xyz = geometric normal (sphere: centre), radius (sphere only)
-__device__ __forceinline__ Surf surface(v3 o, v3 d, float t, uint32_t ref, float hu, float hv, float4 s0, float radius) {
+__device__ __forceinline__ Surf surface(v3 o, v3 d, float t, uint32_t ref, float4 s0, float radius) {
     Surf s;
     s.pos = o + d * t;                                             // RF:304,318
     if (ref_type(ref) == PRIM_SPHERE) {
@@ -588,12 +600,10 @@ __device__ __forceinline__ Surf surface(v3 o, v3 d, float t, uint32_t ref, float
         s.n = normalize(s.pos - ctr);                              // RF:305
         s.inside = length(o - ctr) <= radius;                      // RF:308
         if (s.inside) s.n = s.n * -1.0f;                           // RF:309
-        s.u = 0.0f; s.v = 0.0f;
     } else {
         v3 nor = V(s0.x, s0.y, s0.z);                              // RF:319 for quads, stored at upload
         s.n = dot(nor, d) < 0.0f ? nor : -nor;                     // faceforward, RF:320
         s.inside = false;
-        s.u = hu; s.v = hv;                                        // quads: uv; triangles: barycentrics
     }
     return s;
 }
@@ -656,30 +666,30 @@ __device__ __forceinline__ float fresnel(float iori, float iort, float cosi, flo
 
 constexpr uint32_t PATH_DEAD = 0xFFFFFFFFu;
 
-// one queue entry with its hit record, as shade reads them
-struct ShadeIn { float4 od; float2 d2; float4 tp; float4 hr; };
-__device__ __forceinline__ ShadeIn shade_load(const RayQueue &q, const float4 *hits, uint32_t i) {
-    ShadeIn in; in.od = q.od[i]; in.d2 = q.d2[i]; in.tp = q.tp[i]; in.hr = hits[i];
+// one queue entry (ray, closest hit, throughput and path), as shade reads it
+struct ShadeIn { float4 od; float4 dt; float4 tp; };
+__device__ __forceinline__ ShadeIn shade_load(const RayQueue &q, uint32_t i) {
+    ShadeIn in; in.od = q.od[i]; in.dt = q.dt[i]; in.tp = q.tp[i];
     return in;
 }
 
 // ------------------------------------------------------------------ shade
 // One lane per traced ray. MODE selects the walk: RF:355-407 (path traced), RF:341-353 (AO),
 // RF:409-415 (ZDepth). A finished path writes its colour to raw[path]; a continuing one is
-// pushed to qout (fused compaction) or written back in place for k_compact. With `hits_out` (fused compaction
-// only) the pushed ray also gets its flat-primitive hit record, in a hit array other than the one being read.
+// pushed to qout (fused compaction) or written back in place for k_compact. With `flat` (fused compaction
+// only) the pushed ray leaves with its flat-primitive hit in its entry, otherwise with a miss.
 //
-// The kernel lives on memory latency, so the chain of dependent fetches per ray is kept short: queue entry and
-// hit record -> ONE shading record (surface and material together) -> texel. The next iteration's queue entry
+// The kernel lives on memory latency and bandwidth: 48 bytes per ray come in and 48 go out, and the chain of
+// dependent fetches is kept short: queue entry -> ONE shading record (surface and material together) -> texel. The next iteration's queue entry
 // is requested before this iteration's work starts, and the queue-tail atomic is issued as soon as the lanes
 // know whether they go on, so that its round trip runs under the flat-primitive tests.
 #ifndef KL_SHADE_MIN_WAVES
 #define KL_SHADE_MIN_WAVES 1
 #endif
 template <int MODE>
-__global__ __launch_bounds__(256, KL_SHADE_MIN_WAVES) void k_shade(SceneDev sc, FrameDev f, RayQueue qin, const float4 *hits,
+__global__ __launch_bounds__(256, KL_SHADE_MIN_WAVES) void k_shade(SceneDev sc, FrameDev f, RayQueue qin,
                                                const uint32_t *counts_in, RayQueue qout, uint32_t *counts_out,
-                                               float4 *raw, uint32_t bounce, uint32_t fused, float4 *hits_out) {
+                                               float4 *raw, uint32_t bounce, uint32_t fused, uint32_t flat) {
     // block b works on segment b % nseg; survivors stay in their segment
     const uint32_t seg = blockIdx.x % f.nseg, sub = blockIdx.x / f.nseg, nsub = gridDim.x / f.nseg;
     const uint32_t count = counts_in[seg * CTR_STRIDE];
@@ -689,20 +699,20 @@ __global__ __launch_bounds__(256, KL_SHADE_MIN_WAVES) void k_shade(SceneDev sc, 
     const uint32_t wave = (sub * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = lane_id();
     ShadeIn nxt;
-    nxt.od = make_float4(0, 0, 0, 0); nxt.d2 = make_float2(0, 0); nxt.tp = make_float4(0, 0, 0, 0); nxt.hr = make_float4(0, 0, 0, 0);
-    if (wave * 64u + lane < count) nxt = shade_load(qin, hits, seg_base + wave * 64u + lane);
+    nxt.od = make_float4(0, 0, 0, 0); nxt.dt = make_float4(0, 0, 0, 0); nxt.tp = make_float4(0, 0, 0, 0);
+    if (wave * 64u + lane < count) nxt = shade_load(qin, seg_base + wave * 64u + lane);
     for (uint32_t base = wave * 64u; base < count; base += nwaves * 64u) {
         const uint32_t i = seg_base + base + lane;
         const bool valid = base + lane < count;
         const ShadeIn in = nxt;
         {   // the queue entry of the next iteration, in flight while this one is worked on
             const uint32_t nb = base + nwaves * 64u + lane;
-            if (nb < count) nxt = shade_load(qin, hits, seg_base + nb);
+            if (nb < count) nxt = shade_load(qin, seg_base + nb);
         }
         bool alive = false;
-        v3 o = V(in.od.x, in.od.y, in.od.z), d = V(in.od.w, in.d2.x, in.d2.y), thr = V(in.tp.x, in.tp.y, in.tp.z);
+        v3 o = V(in.od.x, in.od.y, in.od.z), d = V(in.od.w, in.dt.x, in.dt.y), thr = V(in.tp.x, in.tp.y, in.tp.z);
         const uint32_t path = valid ? __float_as_uint(in.tp.w) : PATH_DEAD;
-        const float t = in.hr.x; const uint32_t ref = __float_as_uint(in.hr.y);
+        const float t = in.dt.z; const uint32_t ref = __float_as_uint(in.dt.w);
         // the shading record of the primitive that was hit: the only fetch between the hit record and the texel
         const bool hit = valid && !(t >= f.max_dist) && MODE != KL_MODE_Z;
         float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
@@ -721,7 +731,7 @@ __global__ __launch_bounds__(256, KL_SHADE_MIN_WAVES) void k_shade(SceneDev sc, 
             } else if (MODE == KL_MODE_AO) {
                 if (!(t >= f.max_dist)) {
                     if (bounce == 0) {
-                        Surf s = surface(o, d, t, ref, in.hr.z, in.hr.w, s0, s2.z);
+                        Surf s = surface(o, d, t, ref, s0, s2.z);
                         d = cone_roughness(s.n, 10.0f, r);            // RF:348: theta is 10 radians
                         o = s.pos + d * f.eps;                        // RF:349
                         done = false;
@@ -734,16 +744,19 @@ __global__ __launch_bounds__(256, KL_SHADE_MIN_WAVES) void k_shade(SceneDev sc, 
                 if (t >= f.max_dist) {
                     col = thr * environment(sc, f, d);                // RF:362-364
                 } else {
-                    Surf s = surface(o, d, t, ref, in.hr.z, in.hr.w, s0, s2.z);
+                    Surf s = surface(o, d, t, ref, s0, s2.z);
                     const int mtype = __float_as_int(s0.w);
                     const v3 mcol = V(s1.x, s1.y, s1.z);
                     if (mtype == KL_DIFFUSE || mtype == KL_TEXTURED) {           // RF:365-378
                         if (mtype == KL_TEXTURED) {
-                            float tu = s.u, tv = s.v;
+                            // the hit's (u, v): stored for textured quads (uv) and triangles (barycentrics); Hit_UV of a
+                            // sphere is (0, 0)
+                            const float2 huv = ref_type(ref) == PRIM_SPHERE ? make_float2(0.0f, 0.0f) : qin.uv[i];
+                            float tu = huv.x, tv = huv.y;
                             if (ref_type(ref) == PRIM_TRI) {          // texture coordinates from the corners' (s2.zw, s3.xy, s3.zw)
-                                float w = (1.0f - s.u) - s.v;
-                                tu = (s2.z * w + s3.x * s.u) + s3.z * s.v;
-                                tv = (s2.w * w + s3.y * s.u) + s3.w * s.v;
+                                float w = (1.0f - huv.x) - huv.y;
+                                tu = (s2.z * w + s3.x * huv.x) + s3.z * huv.y;
+                                tv = (s2.w * w + s3.y * huv.x) + s3.w * huv.y;
                             }
                             col = thr * tex_fetch(sc, KL_TEX_ALBEDO, tu, tv);
                         } else {
@@ -789,21 +802,21 @@ __global__ __launch_bounds__(256, KL_SHADE_MIN_WAVES) void k_shade(SceneDev sc, 
             const uint32_t leader = m ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
             if (m != 0ull && lane == leader) tail = atomicAdd(count_out, (uint32_t)__popcll(m));
             if (valid && done) raw[path] = make_float4(col.x, col.y, col.z, 1.0f);
-            float4 fh = make_float4(0, 0, 0, 0);
-            if (alive && hits_out) fh = flat_hit(sc, f, o, d);
+            Hit fh; fh.t = f.max_dist; fh.ref = REF_MISS; fh.u = fh.v = 0.0f; fh.id = 0xFFFFFFFFu; fh.uvf = 0u;
+            if (alive && flat) fh = flat_hit(sc, f, o, d);
             if (m != 0ull) {
                 const uint32_t slot_out = seg_base + (uint32_t)__shfl((int)tail, (int)leader) + mask_rank(m);
                 if (alive) {
                     qout.od[slot_out] = make_float4(o.x, o.y, o.z, d.x);
-                    qout.d2[slot_out] = make_float2(d.y, d.z);
+                    qout.dt[slot_out] = make_float4(d.y, d.z, fh.t, __uint_as_float(fh.ref));
                     qout.tp[slot_out] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(path));
-                    if (hits_out) hits_out[slot_out] = fh;
+                    if (fh.uvf) qout.uv[slot_out] = make_float2(fh.u, fh.v);
                 }
             }
         } else if (valid) {
             if (done) raw[path] = make_float4(col.x, col.y, col.z, 1.0f);
             qin.od[i] = make_float4(o.x, o.y, o.z, d.x);
-            qin.d2[i] = make_float2(d.y, d.z);
+            qin.dt[i] = make_float4(d.y, d.z, f.max_dist, __uint_as_float(REF_MISS));
             qin.tp[i] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(alive ? path : PATH_DEAD));
         }
     }
@@ -823,7 +836,7 @@ __global__ __launch_bounds__(256) void k_compact(FrameDev f, RayQueue qin, const
         bool alive = false;
         if (base + lane_id() < count) { tp = qin.tp[i]; alive = __float_as_uint(tp.w) != PATH_DEAD; }
         uint32_t dst = seg_base + wave_reserve(counts_out + seg * CTR_STRIDE, alive);
-        if (alive) { qout.od[dst] = qin.od[i]; qout.d2[dst] = qin.d2[i]; qout.tp[dst] = tp; }
+        if (alive) { qout.od[dst] = qin.od[i]; qout.dt[dst] = qin.dt[i]; qout.tp[dst] = tp; }
     }
 }
 
@@ -883,14 +896,15 @@ __global__ __launch_bounds__(256) void k_resolve(const float4 *acc, uchar4 *out,
     }
 }
 
-// unpack hit records of kl_trace_rays into (t, declaration-order id, uv)
-__global__ void k_unpack_hits(SceneDev sc, const float4 *hits, uint32_t n, float *t, uint32_t *prim, float2 *uv) {
+// unpack the hits of kl_trace_rays' queue into (t, declaration-order id, uv)
+__global__ void k_unpack_hits(SceneDev sc, RayQueue q, uint32_t n, float *t, uint32_t *prim, float2 *uv) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float4 h = hits[i];
-    uint32_t ref = __float_as_uint(h.y), id = 0xFFFFFFFFu;
+    const float4 dt = q.dt[i];
+    uint32_t ref = __float_as_uint(dt.w), id = 0xFFFFFFFFu;
     if (ref != REF_MISS) id = ref_id(sc, ref);
-    t[i] = h.x; prim[i] = id; uv[i] = make_float2(h.z, h.w);
+    t[i] = dt.z; prim[i] = id;
+    uv[i] = (ref != REF_MISS && ref_type(ref) != PRIM_SPHERE) ? q.uv[i] : make_float2(0.0f, 0.0f);   // the queue was traced with all_uv
 }
 
 // ------------------------------------------------------------------ launch wrappers
@@ -909,39 +923,39 @@ static inline uint32_t seg_grid(const FrameDev &f, uint32_t max_rays, uint32_t c
 }
 
 void launch_generate(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q, uint32_t *count0,
-                     const float4 *seed_hits, uint32_t seed_segcap, float4 *hits, bool flat) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(f.nslots * f.npl, lc.cus * 8u)), dim3(256), 0, s, sc, f, q, count0, seed_hits, seed_segcap,
-                       hits, flat ? 1u : 0u);
+                     bool flat, RayQueue seed, uint32_t seed_segcap) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(f.nslots * f.npl, lc.cus * 8u)), dim3(256), 0, s, sc, f, q, count0, seed, seed_segcap,
+                       flat ? 1u : 0u);
 }
 size_t intersect_overflow_ints(const LaunchCfg &lc) {
     return (size_t)lc.cus * lc.isect_blocks_per_cu * ISECT_WAVES * ISECT_OVF_STACK * 64u;
 }
 bool scene_has_flat(const SceneDev &sc) { return (sc.flat_count[0] + sc.flat_count[1] + sc.flat_count[2]) != 0u; }
 // the coherent pass over the flat primitives; precedes launch_intersect when the tree is used and scene_has_flat()
-void launch_intersect_flat(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q, float4 *hits,
+void launch_intersect_flat(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q,
                            const uint32_t *counts, Counters *cn, bool stats, uint32_t max_rays) {
-    hipLaunchKernelGGL(k_intersect_flat, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, hits, counts, cn, stats ? 1u : 0u);
+    hipLaunchKernelGGL(k_intersect_flat, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, counts, cn, stats ? 1u : 0u);
 }
-void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q, float4 *hits,
+void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q,
                       const uint32_t *counts, uint32_t *heads, Counters *cn, int *overflow, bool bvh, bool stats, uint32_t max_rays,
                       bool flat_by_producer) {
     if (!bvh) {
-        hipLaunchKernelGGL(k_intersect_brute, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, hits, counts, cn);
+        hipLaunchKernelGGL(k_intersect_brute, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, counts, cn);
         return;
     }
-    const uint32_t seeded = scene_has_flat(sc) ? (flat_by_producer ? 2u : 1u) : 0u;
+    const uint32_t tally_flat = (scene_has_flat(sc) && flat_by_producer) ? 1u : 0u;
     uint32_t blocks = seg_grid(f, max_rays, lc.cus * lc.isect_blocks_per_cu, ISECT_CHUNK * ISECT_WAVES);
-    if (stats) hipLaunchKernelGGL(k_intersect_bvh<true>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, seeded, counts, heads, cn, overflow);
-    else hipLaunchKernelGGL(k_intersect_bvh<false>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, hits, seeded, counts, heads, cn, overflow);
+    if (stats) hipLaunchKernelGGL(k_intersect_bvh<true>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, tally_flat, counts, heads, cn, overflow);
+    else hipLaunchKernelGGL(k_intersect_bvh<false>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, tally_flat, counts, heads, cn, overflow);
 }
-void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin, const float4 *hits,
+void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin,
                   const uint32_t *count_in, RayQueue qout, uint32_t *count_out, float4 *raw, uint32_t bounce, bool fused,
-                  uint32_t max_rays, float4 *hits_out) {
+                  uint32_t max_rays, bool flat) {
     dim3 g(seg_grid(f, max_rays, lc.cus * 8u, 256u)), b(256);
-    uint32_t fu = fused ? 1u : 0u;
-    if (f.mode == KL_MODE_PT) hipLaunchKernelGGL(k_shade<KL_MODE_PT>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu, fused ? hits_out : nullptr);
-    else if (f.mode == KL_MODE_AO) hipLaunchKernelGGL(k_shade<KL_MODE_AO>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu, fused ? hits_out : nullptr);
-    else hipLaunchKernelGGL(k_shade<KL_MODE_Z>, g, b, 0, s, sc, f, qin, hits, count_in, qout, count_out, raw, bounce, fu, fused ? hits_out : nullptr);
+    const uint32_t fu = fused ? 1u : 0u, fl = (fused && flat) ? 1u : 0u;
+    if (f.mode == KL_MODE_PT) hipLaunchKernelGGL(k_shade<KL_MODE_PT>, g, b, 0, s, sc, f, qin, count_in, qout, count_out, raw, bounce, fu, fl);
+    else if (f.mode == KL_MODE_AO) hipLaunchKernelGGL(k_shade<KL_MODE_AO>, g, b, 0, s, sc, f, qin, count_in, qout, count_out, raw, bounce, fu, fl);
+    else hipLaunchKernelGGL(k_shade<KL_MODE_Z>, g, b, 0, s, sc, f, qin, count_in, qout, count_out, raw, bounce, fu, fl);
 }
 void launch_compact(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, RayQueue qin, const uint32_t *count_in, RayQueue qout,
                     uint32_t *count_out, uint32_t max_rays) {
@@ -955,8 +969,8 @@ void launch_accumulate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, co
 void launch_resolve(hipStream_t s, const LaunchCfg &lc, const float4 *acc, uchar4 *out, uint32_t n, uint32_t tonemap) {
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(n, lc.cus * 8u)), dim3(256), 0, s, acc, out, n, tonemap);
 }
-void launch_unpack_hits(hipStream_t s, const SceneDev &sc, const float4 *hits, uint32_t n, float *t, uint32_t *prim, float2 *uv) {
-    hipLaunchKernelGGL(k_unpack_hits, dim3((n + 255u) / 256u), dim3(256), 0, s, sc, hits, n, t, prim, uv);
+void launch_unpack_hits(hipStream_t s, const SceneDev &sc, RayQueue q, uint32_t n, float *t, uint32_t *prim, float2 *uv) {
+    hipLaunchKernelGGL(k_unpack_hits, dim3((n + 255u) / 256u), dim3(256), 0, s, sc, q, n, t, prim, uv);
 }
 
 }  // namespace kl

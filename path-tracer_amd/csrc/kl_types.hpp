@@ -15,9 +15,10 @@ namespace kl {
 // lane stands on an inner node or on a primitive.
 //   node:   four children with 8-bit boxes, see "4-wide node" below
 //   sphere: q0 = (c.xyz, r)          q1 = (id bits, material bits, 0, 0)
-//   quad:   q0 = (v0.xyz, v1.x)      q1 = (v1.yz, v2.xy)   q2 = (v2.z, v3.xyz)   q3 = (id bits, material bits, 0, 0)
-//   tri:    q0 = (v0.xyz, e1.x)      q1 = (e1.yz, e2.xy)   q2 = (e2.z, id bits, material bits, 0)   q3 = 0
-// id = declaration-order primitive id (spheres, then quads, then triangles).
+//   quad:   q0 = (v0.xyz, v1.x)      q1 = (v1.yz, v2.xy)   q2 = (v2.z, v3.xyz)   q3 = (id bits, material bits, uv flag, 0)
+//   tri:    q0 = (v0.xyz, e1.x)      q1 = (e1.yz, e2.xy)   q2 = (e2.z, id bits, material bits, uv flag)   q3 = 0
+// id = declaration-order primitive id (spheres, then quads, then triangles). uv flag = 1 if shading the primitive
+// reads the hit's (u, v), i.e. its material is TEXTURED; only then does a hit store them.
 //
 // Shading reads a second array, one 64-byte SHADING record per primitive (index = record index - base[0]),
 // holding everything the shade stage needs about the surface it hit, material included, so that one fetch
@@ -67,7 +68,7 @@ struct SceneDev {
     // pass (k_intersect_flat) whose result seeds the traversal's closest distance.
     uint32_t flat_start[3], flat_count[3];   // record index of the first flat primitive of a type, how many
     // per flat quad, the ray-independent part of the quad test evaluated once at upload (5 float4 each):
-    //   F0 = (v0.xyz, nor[id])  F1 = (nor.xyz, k2)  F2 = (ka.xy, kb.xy)  F3 = (kg.xy, idu | idv << 2, 0)  F4 = (id bits, 0, 0, 0)
+    //   F0 = (v0.xyz, nor[id])  F1 = (nor.xyz, k2)  F2 = (ka.xy, kb.xy)  F3 = (kg.xy, idu | idv << 2, 0)  F4 = (id bits, uv flag, 0, 0)
     const float4 *flatq;
     const float4 *shrec;     // shading records, 4 float4 per primitive
     // textures, RGBA8, rows as uploaded
@@ -89,6 +90,7 @@ struct FrameDev {
     uint32_t max_bounces, max_frames;
     float eps, max_dist, ao_length, hdri_strength;
     uint32_t nseg, segcap;              // queue segmentation, see RayQueue
+    uint32_t all_uv;                    // 1: every hit stores its (u, v), not only those whose shading reads them (caller rays)
     // division by npl, width and band_rows as multiply-high + add + shift (exact for dividends below 2^31)
     uint32_t div_npl[2], div_width[2], div_band[2];
 };
@@ -102,8 +104,12 @@ __host__ __device__ inline void fastdiv_make(uint32_t d, uint32_t out[2]) {
 __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const uint32_t ms[2]) { return (__umulhi(n, ms[0]) + n) >> ms[1]; }
 
 // ---- wavefront queues -------------------------------------------------------------
-// One ray = 40 bytes over three arrays so that every access is a full-width vector load:
-//   od[i] = (o.x, o.y, o.z, d.x)   d2[i] = (d.y, d.z)   tp[i] = (throughput rgb, path id bits)
+// One ray = 48 bytes over three arrays so that every access is a full-width vector access:
+//   od[i] = (o.x, o.y, o.z, d.x)   dt[i] = (d.y, d.z, t, ref bits)   tp[i] = (throughput rgb, path id bits)
+// (t, ref) is the ray's closest hit so far. The kernel that makes a ray writes the hit among the flat
+// primitives there (or t = max_dist, ref = REF_MISS); the intersect stage overwrites the two words only if it
+// finds something closer; shade reads them. The hit's (u, v) live in uv[i], 8 bytes that are written and read
+// only for primitives whose material is textured (the records' uv flag) — most rays never touch them.
 // path id = slot * npl + local pixel; it also indexes the raw-frame buffer.
 //
 // A queue is `nseg` independent segments of `segcap` entries: ray i of segment s lives at index
@@ -116,10 +122,10 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const uint32_t ms[2]) { 
 constexpr uint32_t CTR_STRIDE = 64;
 struct RayQueue {
     float4 *od;
-    float2 *d2;
+    float4 *dt;
     float4 *tp;
+    float2 *uv;
 };
-// hit[i] = (t, ref bits, u, v) for ray i of the queue that was traced
 struct Counters {            // 64-bit device counters, see kl_counters
     unsigned long long rays, nodes, sphere_tests, quad_tests, tri_tests, lane_active, lane_total, pad;
 };
