@@ -201,6 +201,25 @@ def main():
     samples_total = float(npix) * args.spp * args.steps * world
     value = samples_total / elapsed
 
+    # With the library's default of two batch lanes the traversal launches of the two lanes share the GPU with each
+    # other's shade launches, so a launch bracketed by events lasts longer than the same launch alone. One more step,
+    # untimed, on a single lane gives the kernel's own figure next to the timed region's.
+    isolated = None
+    if tm.intersect_launches and r.get_params().batch_lanes != 1:
+        r.update_params(batch_lanes=1)
+        r.reset_counters()
+        step()
+        fence()
+        cn1, tm1 = r.counters(), r.timing()
+        if tm1.intersect_launches:
+            s1 = tm1.intersect_ms * 1e-3
+            isolated = {"lanes": 1, "launches": int(tm1.intersect_launches), "rays_per_launch": round(cn1.rays / tm1.intersect_launches, 1),
+                        "avg_launch_ms": round(tm1.intersect_ms / tm1.intersect_launches, 4),
+                        "achieved": round(cn1.rays * b_ray / s1 / 1e9, 1), "frac": round(cn1.rays * b_ray / s1 / 1e9 / HBM_PEAK_GBS, 4),
+                        "grays_per_s_in_kernel": round(cn1.rays / s1 / 1e9, 3),
+                        "valu_tflops": round(cn1.rays * f_ray / s1 / 1e12, 2)}
+        r.update_params(batch_lanes=args.lanes)
+
     roofline = None
     if tm.intersect_launches:
         isect_s = tm.intersect_ms * 1e-3
@@ -225,8 +244,9 @@ def main():
                     "intersect_share_of_step": round(isect_s / elapsed, 3), "lane_active_frac": round(lane_active, 3),
                     "grays_per_s_in_kernel": round(rays_rank / isect_s / 1e9, 3),
                     "batch_lanes_param": int(r.get_params().batch_lanes),
-                    "timing_note": "with more than one batch lane the traversal launches of neighbouring batches overlap on the GPU, so an "
-                                   "event-bracketed launch lasts longer than the same launch alone (run --lanes 1 for isolated launches)",
+                    "timing_note": "timed region = library default (two batch lanes): traversal launches run beside the other lane's kernels, so an "
+                                   "event-bracketed launch lasts longer than the same launch alone; `isolated` = one untimed step on a single lane",
+                    "isolated": isolated,
                     # the other ceiling of this kernel: vector fp32. 100 flop per 4-wide node (two 2-child slab tests),
                     # 45 per triangle, 25 per sphere, 90 per quad
                     "valu": {"flop_per_ray": round(f_ray, 1), "achieved": round(rays_rank * f_ray / isect_s / 1e12, 2),

@@ -156,10 +156,22 @@ uint32_t choose_slots(kl_ctx *c) {
 
 uint32_t choose_lanes(kl_ctx *c) {
     uint32_t n = c->params.batch_lanes;
-    // automatic: a second lane pays while batches are small enough for their tails to matter (measured: +6 % at
-    // 8 Mi paths per batch, nothing at 32 Mi, a small loss beyond)
-    if (n == 0) n = (uint64_t)choose_slots(c) * c->npl < (32ull << 20) ? 2u : 1u;
+    // automatic: two. The stages of a batch want different things (traversal: instruction issue and cache latency;
+    // shade: HBM bandwidth), so two batches in flight fill each other's gaps as well as each other's launch tails
+    // (measured at 1080p: +2.8 % over one lane; three or four lanes bring nothing more).
+    if (n == 0) n = 2u;
     return std::min(n, KL_MAX_BATCH_LANES);
+}
+// frames per batch for a call that renders n frames on `lanes` lanes: as many as memory allows (choose_slots), but
+// with automatic sizing and several lanes at most 48 (beyond that two concurrent batches were measured slower than
+// one) and an equal share for every lane, so that no lane idles at the end
+uint32_t frames_per_batch(kl_ctx *c, uint32_t n, uint32_t lanes) {
+    uint32_t cap = choose_slots(c);
+    if (c->params.frames_in_flight != 0 || lanes < 2 || n < 2) return std::max(1u, std::min(cap, n));
+    cap = std::min(cap, 48u);
+    uint32_t nb = (n + cap - 1) / cap;
+    nb = (nb + lanes - 1) / lanes * lanes;
+    return std::max(1u, (n + nb - 1) / nb);
 }
 
 // buffers of the first `lanes` batch lanes (and their streams and events), for batches of up to `frames` frames.
@@ -696,7 +708,7 @@ kl_status kl_render_frames(kl_ctx *c, uint32_t n, uint32_t first_frame) {
     if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");
     if (c->npl == 0 || n == 0) return KL_OK;
     // as many lanes as there are batches to overlap
-    const uint32_t per_batch = std::max(1u, std::min(choose_slots(c), n));
+    const uint32_t per_batch = frames_per_batch(c, n, choose_lanes(c));
     const uint32_t batches = (n + per_batch - 1) / per_batch;
     const uint32_t lanes = std::min(choose_lanes(c), batches);
     kl_status s = ensure_buffers(c, lanes, per_batch);
@@ -729,7 +741,7 @@ kl_status kl_render_frames(kl_ctx *c, uint32_t n, uint32_t first_frame) {
             if (after) KL_HIP(c, hipStreamWaitEvent(L.stream, after, 0));
             launch_accumulate(L.stream, c->lc, f, L.d_raw.p, c->d_acc.p, c->d_last_raw.p, false, c->accum_mode);
         } else {
-            k = std::min(left, c->slots);
+            k = std::min(left, std::min(per_batch, c->slots));
             if (mf) k = std::min(k, mf - frame);
             if ((s = render_batch(c, L, after, frame, k, c->camera_change)) != KL_OK) return s;
             c->paths_total += (uint64_t)k * c->npl;

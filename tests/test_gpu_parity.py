@@ -88,7 +88,7 @@ def test_builtin_against_llvmpipe_goldens(size, textures):
 
 def test_config1_16spp(textures, oracle_builtin):
     """BASELINE config 1: 640x360, 16 spp, path traced, 32-bounce cap, running mean"""
-    with make_renderer(640, 360, textures, trace_primary_per_frame=1) as r:
+    with make_renderer(640, 360, textures, trace_primary_per_frame=1, frames_in_flight=16) as r:    # one batch of 16 frames
         r.set_mode(kl.MODE_PT)
         r.render_frames(16)
         assert r.frame == 16
