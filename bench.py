@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--builder", choices=("host", "gpu"), default="host",
                     help="BVH builder: host = binned SAH on the host cores (headline), gpu = Morton-ordered tree built on the GPU")
+    ap.add_argument("--skip-isolated", action="store_true", help="skip the extra untimed single-lane step behind roofline.isolated")
     ap.add_argument("--skip-shared", action="store_true", help="skip the second timed pass (camera-ray hits shared by a batch's frames)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events around the intersect kernel")
     args = ap.parse_args()
@@ -205,7 +206,7 @@ def main():
     # other's shade launches, so a launch bracketed by events lasts longer than the same launch alone. One more step,
     # untimed, on a single lane gives the kernel's own figure next to the timed region's.
     isolated = None
-    if tm.intersect_launches and r.get_params().batch_lanes != 1:
+    if tm.intersect_launches and r.get_params().batch_lanes != 1 and not args.skip_isolated:
         r.update_params(batch_lanes=1)
         r.reset_counters()
         step()

@@ -92,12 +92,13 @@ typedef struct kl_params {
     float ao_length;           /* AO_LENGTH, 1 */
     float hdri_strength;       /* HDRI_STRENGTH, 1 */
     uint32_t accel;            /* KL_ACCEL_* */
-    uint32_t frames_in_flight; /* frames traced together as one wavefront batch (0 = choose: as many as a quarter of the free memory holds, up to 64) */
+    uint32_t frames_in_flight; /* frames traced together as one wavefront batch (0 = choose: as many as a quarter of the free memory holds, up to 64,
+                                  with several lanes up to 48 and the call's frames shared equally among the lanes) */
     uint32_t fused_compaction; /* 1: shade pushes survivors itself; 0: separate compact kernel */
     uint32_t collect_stats;    /* 1: traversal kernels count nodes/primitives/active lanes (slower) */
     uint32_t profile_kernels;  /* 1: HIP events around every intersect launch, see kl_get_timing */
     uint32_t batch_lanes;      /* batches traced concurrently on separate HIP streams, each with its own queues: 0 = choose
-                                  (2 while batches are small, else 1), 1 = one stream, at most 4. The image does not depend on it (batches accumulate in frame order). */
+                                  (two), 1 = one stream, at most 4. The image does not depend on it (batches accumulate in frame order). */
     uint32_t trace_primary_per_frame; /* 0: the camera ray of a pixel, which is the same in every frame (RawFrame.glsl:436 adds no
                                   jitter at SPP = 1), is traced once per batch and its hit shared by the batch's frames;
                                   1: traced again for every frame, as the shader does. The image is the same either way. */

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 mkdir -p $out
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- \
-  python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --skip-shared > $out/bench_under_rocprof.json 2> $out/trace.log
+  python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --skip-shared --skip-isolated > $out/bench_under_rocprof.json 2> $out/trace.log
 python3 tools/rocpd_summary.py $(find $out/trace -name '*.db' | head -1) > $out/kernel_stats.md
 tools/pmc_pass.sh ${tag}_fetch FETCH_SIZE
 tools/pmc_pass.sh ${tag}_write WRITE_SIZE
