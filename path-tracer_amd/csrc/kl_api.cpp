@@ -273,7 +273,7 @@ bool use_bvh(const kl_ctx *c) {
     return c->n_prims > KL_BRUTE_AUTO_LIMIT;
 }
 
-// `flat_done`: the kernel that produced the rays has already written their flat-primitive hit records
+// `flat_done`: the kernel that produced the rays has already written their flat-primitive hits into the queue entries
 kl_status timed_intersect(kl_ctx *c, BatchLane &L, const FrameDev &f, RayQueue q, uint32_t *count, uint32_t *head, uint32_t max_rays,
                           bool flat_done) {
     hipEvent_t a = nullptr, b = nullptr;

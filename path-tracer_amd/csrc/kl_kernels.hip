@@ -1,13 +1,16 @@
 // Wavefront path-tracing kernels for gfx950 (wave64).
 //
-//   generate  : camera rays for every (frame slot, pixel) of a batch       -> ray queue 0
-//   intersect : closest hit per ray; persistent wave64 workgroups pull ray
+//   generate  : camera rays for every (frame slot, pixel) of a batch, each with its hit
+//               among the flat primitives                                   -> ray queue 0
+//   intersect : closest hit per ray, written into the ray's queue entry when the
+//               tree holds something closer; persistent wave64 workgroups pull ray
 //               ranges from a global counter and refill idle lanes; SAH-BVH
 //               traversal with a per-lane stack in LDS (or a flat loop for
-//               scenes of a few primitives)                                 -> hit records
+//               scenes of a few primitives)
 //   shade     : surface reconstruction + BSDF / environment / texture; the
 //               surviving rays are compacted with ballot + popcount into the
-//               next queue (or left in place for the separate compact kernel)
+//               next queue, their flat-primitive hits with them (or left in
+//               place for the separate compact kernel)
 //   compact   : stand-alone stream compaction of a shaded queue
 //   accumulate: running mean (or sum) over the frames of the batch, in order
 //
@@ -118,12 +121,12 @@ __device__ __forceinline__ uint32_t ref_id(const SceneDev &sc, uint32_t ref) {
     const uint32_t type = ref_type(ref);
     return type == PRIM_SPHERE ? __float_as_uint(p[1].x) : (type == PRIM_QUAD ? __float_as_uint(p[3].x) : __float_as_uint(p[2].y));
 }
-// h.id of a hit taken over from a hit record: not known, and fetched only if an exact tie asks for it
+// h.id of a hit taken over from a queue entry: not known, and fetched only if an exact tie asks for it
 constexpr uint32_t ID_UNKNOWN = 0xFFFFFFFEu;
 
 // acceptance rule of RF:302,316 (`t < best && t > 0.001`); on exactly equal t the lower
 // declaration-order id wins, which is what the shader's in-order loop with a strict `<` does.
-// `lazy`: h.id may be ID_UNKNOWN (h came from a hit record, which has no room for the id).
+// `lazy`: h.id may be ID_UNKNOWN (h came from a queue entry, which has no room for the id).
 __device__ __forceinline__ void accept(Hit &h, float t, uint32_t ref, uint32_t id, float u, float v, uint32_t uvf, const SceneDev *lazy = nullptr) {
     if (!(t > 0.001f)) return;
     bool take = t < h.t;
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(256, KL_SHADE_MIN_WAVES) void k_shade(SceneDev sc, 
         v3 o = V(in.od.x, in.od.y, in.od.z), d = V(in.od.w, in.dt.x, in.dt.y), thr = V(in.tp.x, in.tp.y, in.tp.z);
         const uint32_t path = valid ? __float_as_uint(in.tp.w) : PATH_DEAD;
         const float t = in.dt.z; const uint32_t ref = __float_as_uint(in.dt.w);
-        // the shading record of the primitive that was hit: the only fetch between the hit record and the texel
+        // the shading record of the primitive that was hit: the only fetch between the queue entry and the texel
         const bool hit = valid && !(t >= f.max_dist) && MODE != KL_MODE_Z;
         float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
         if (hit) {

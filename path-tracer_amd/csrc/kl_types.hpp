@@ -22,7 +22,7 @@ namespace kl {
 //
 // Shading reads a second array, one 64-byte SHADING record per primitive (index = record index - base[0]),
 // holding everything the shade stage needs about the surface it hit, material included, so that one fetch
-// follows the hit record instead of a chain record -> material -> triangle uvs:
+// follows the hit instead of a chain record -> material -> triangle uvs:
 //   s0 = (n.xyz, material type bits)   n = the geometric normal in the shader's arithmetic: quads
 //        normalize(cross(v2 - v1, v3 - v1)) (RawFrame.glsl:319), triangles normalize(cross(e1, e2));
 //        spheres: the centre instead (their normal depends on the hit point)
