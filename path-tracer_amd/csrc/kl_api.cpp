@@ -551,11 +551,16 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     // >= 2 % of the scene's (at most 32 of them: walls, floors, sky domes) are tested outside the tree
     const bool small = ns + nq + nt <= KL_BRUTE_AUTO_LIMIT;
     uint32_t builder = KL_BUILD_HOST_SAH;
+    GpuScene packed;
+    bool on_gpu = false;                // records already written on the device by the builder
     if (c->params.bvh_builder == KL_BUILD_GPU_LBVH && !small) {
         std::string why;
-        const LbvhResult r = build_bvh_gpu(c->stream, s, ns, q, nq, t, nt, bvh, 0.02f, 32, why);
+        // the GPU builder also writes the records there (KL_PACK_HOST=1: pack them here instead, from its tree)
+        const char *ph = std::getenv("KL_PACK_HOST");
+        const bool pack_here = ph && ph[0] == '1';
+        const LbvhResult r = build_bvh_gpu(c->stream, s, ns, q, nq, t, nt, bvh, 0.02f, 32, why, m, nm, pack_here ? nullptr : &packed);
         if (r == LBVH_HIP_ERROR) return fail(c, KL_E_DEVICE, "GPU BVH build: " + why);
-        if (r == LBVH_OK) builder = KL_BUILD_GPU_LBVH;      // LBVH_TOO_DEEP: the host builder below
+        if (r == LBVH_OK) { builder = KL_BUILD_GPU_LBVH; on_gpu = !pack_here; }      // LBVH_TOO_DEEP: the host builder below
     }
     if (builder == KL_BUILD_HOST_SAH) {
         build_bvh(s, ns, q, nq, t, nt, bvh, threads, small ? 0.0f : 0.02f, 32);
@@ -563,18 +568,18 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     }
     // one array of 64-byte records: nodes, then spheres, quads, triangles in leaf order (layout: kl_types.hpp)
     auto bits = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
-    const uint32_t n_nodes = (uint32_t)(bvh.nodes4.size() / 16);
+    const uint32_t n_nodes = on_gpu ? bvh.stats.nodes : (uint32_t)(bvh.nodes4.size() / 16);
     const uint32_t base[3] = { n_nodes, n_nodes + ns, n_nodes + ns + nq };
     const size_t n_rec = std::max<size_t>((size_t)n_nodes + ns + nq + nt, 1);   // record 0 always exists
     if (n_rec >= MAX_RECORDS) return fail(c, KL_E_LIMIT, "nodes + primitives exceed 2^26 records");
     // (plain arrays: every word is written by the packing loops below, a zero fill of a gigabyte first would cost as much as they do)
     const float4 zero4 = make_float4(0, 0, 0, 0);
-    std::unique_ptr<float4[]> rec(new (std::nothrow) float4[n_rec * 4]);
+    std::unique_ptr<float4[]> rec(on_gpu ? nullptr : new (std::nothrow) float4[n_rec * 4]);
     // shading records (layout: kl_types.hpp), one per primitive in record order
     const size_t n_shrec = std::max<size_t>((size_t)ns + nq + nt, 1);
-    std::unique_ptr<float4[]> shrec(new (std::nothrow) float4[n_shrec * 4]);
-    if (!rec || !shrec) return fail(c, KL_E_NOMEM, "host memory for the scene records");
-    for (int k = 0; k < 4; k++) { rec[k] = zero4; shrec[k] = zero4; }      // record 0 exists even in an empty scene
+    std::unique_ptr<float4[]> shrec(on_gpu ? nullptr : new (std::nothrow) float4[n_shrec * 4]);
+    if (!on_gpu && (!rec || !shrec)) return fail(c, KL_E_NOMEM, "host memory for the scene records");
+    if (!on_gpu) for (int k = 0; k < 4; k++) { rec[k] = zero4; shrec[k] = zero4; }      // record 0 exists even in an empty scene
     auto shade_rec = [&](size_t prim, v3 n, const kl_material &mt, float4 s2, float4 s3) {
         float4 *r = &shrec[4 * prim];
         r[0] = make_float4(n.x, n.y, n.z, bits((uint32_t)mt.type));
@@ -587,6 +592,7 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
         uint32_t lv = (uint32_t)~child, type = (lv >> 29) & 3u, cnt = ((lv >> 26) & 7u) + 1u, start = lv & 0x3FFFFFFu;
         return make_leaf(type, base[type] + start, cnt);
     };
+    if (!on_gpu) {
     parallel_for(n_nodes, threads, [&](uint32_t kb, uint32_t ke) {
         for (uint32_t k = kb; k < ke; k++) {
             uint32_t w[16]; std::memcpy(w, &bvh.nodes4[(size_t)k * 16], sizeof w);
@@ -594,9 +600,6 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
             std::memcpy(&rec[4 * (size_t)k], w, sizeof w);
         }
     });
-    const int32_t tree_root = bvh.root4;
-    bvh.stats.nodes = n_nodes; bvh.stats.max_depth = bvh.depth4; bvh.stats.node_bytes = (uint64_t)n_nodes * 64u;
-    bvh.stats.builder = builder;
     parallel_for(ns, threads, [&](uint32_t kb, uint32_t ke) {
         for (uint32_t k = kb; k < ke; k++) {
             const kl_sphere &x = s[bvh.sph_order[k]];
@@ -633,11 +636,15 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
             shade_rec((size_t)ns + nq + k, nor, m[x.material], make_float4(0, 0, x.uv0[0], x.uv0[1]), make_float4(x.uv1[0], x.uv1[1], x.uv2[0], x.uv2[1]));
         }
     });
+    }
+    const int32_t tree_root = bvh.root4;
+    bvh.stats.nodes = n_nodes; bvh.stats.max_depth = bvh.depth4; bvh.stats.node_bytes = (uint64_t)n_nodes * 64u;
+    bvh.stats.builder = builder;
     // ray-independent terms of the quad test (RawFrame.glsl:219-244) for the flat quads, in the test's own operations
     const uint32_t nfq = bvh.flat_count[PRIM_QUAD];
     std::vector<float4> flatq((size_t)nfq * 5);
     for (uint32_t k = 0; k < nfq; k++) {
-        const uint32_t qi = bvh.quad_order[bvh.flat_start[PRIM_QUAD] + k];
+        const uint32_t qi = on_gpu ? packed.flat_quads[k] : bvh.quad_order[bvh.flat_start[PRIM_QUAD] + k];
         const kl_quad &x = q[qi];
         v3 v0 = V(x.v0[0], x.v0[1], x.v0[2]);
         v3 a = V(x.v1[0], x.v1[1], x.v1[2]) - v0, b = V(x.v3[0], x.v3[1], x.v3[2]) - v0, cc = V(x.v2[0], x.v2[1], x.v2[2]) - v0;
@@ -657,8 +664,13 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     }
     kl_status st;
     if ((st = upload(c, c->d_flatq, flatq.data(), flatq.size())) != KL_OK) return st;
-    if ((st = upload(c, c->d_rec, rec.get(), n_rec * 4)) != KL_OK) return st;
-    if ((st = upload(c, c->d_shrec, shrec.get(), n_shrec * 4)) != KL_OK) return st;
+    if (on_gpu) {                                    // the builder's buffers become the scene's
+        c->d_rec.release(); c->d_rec.p = (float4 *)packed.d_rec; c->d_rec.n = packed.n_rec * 4; packed.d_rec = nullptr;
+        c->d_shrec.release(); c->d_shrec.p = (float4 *)packed.d_shrec; c->d_shrec.n = packed.n_shrec * 4; packed.d_shrec = nullptr;
+    } else {
+        if ((st = upload(c, c->d_rec, rec.get(), n_rec * 4)) != KL_OK) return st;
+        if ((st = upload(c, c->d_shrec, shrec.get(), n_shrec * 4)) != KL_OK) return st;
+    }
     KL_HIP(c, hipStreamSynchronize(c->stream));     // the host vectors go out of scope below
     c->sc.rec = c->d_rec.p; c->sc.root = patch_child(tree_root); c->sc.n_nodes = n_nodes;
     c->sc.shrec = c->d_shrec.p; c->sc.flatq = c->d_flatq.p;

@@ -20,6 +20,7 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include "kl_math.hpp"
 #include "kl_types.hpp"
 
 namespace kl {
@@ -309,6 +310,68 @@ __global__ __launch_bounds__(256) void k_lbvh_collapse(uint32_t begin, uint32_t 
     dst[2] = make_uint4(w[8], w[9], w[10], w[11]); dst[3] = make_uint4(w[12], w[13], w[14], w[15]);
 }
 
+// ---- record packing (the device twin of the host loops in kl_upload_scene: same words, same arithmetic) ----
+__global__ __launch_bounds__(256) void k_lbvh_pack_nodes(const uint32_t *nodes4, uint32_t count4, uint32_t base0, uint32_t base1, uint32_t base2, uint4 *rec) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count4) return;
+    const uint4 *src = (const uint4 *)(nodes4 + (size_t)k * 16);
+    uint4 c = src[3];
+    uint32_t w[4] = { c.x, c.y, c.z, c.w };
+    for (int j = 0; j < 4; j++) {
+        const int32_t child = (int32_t)w[j];
+        if (child < 0) {                                   // a leaf counts within its type: make it a record index
+            const uint32_t lv = (uint32_t)~child, type = (lv >> 29) & 3u, cnt = ((lv >> 26) & 7u) + 1u, start = lv & 0x3FFFFFFu;
+            w[j] = (uint32_t)make_leaf(type, (type == 0u ? base0 : (type == 1u ? base1 : base2)) + start, cnt);
+        }
+    }
+    uint4 *dst = rec + (size_t)k * 4;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ void pack_shade(float4 *r, v3 n, const kl_material &mt, float s2z, float s2w, float4 s3) {
+    r[0] = make_float4(n.x, n.y, n.z, __int_as_float(mt.type));
+    r[1] = make_float4(mt.color[0], mt.color[1], mt.color[2], mt.emissive);
+    r[2] = make_float4(mt.roughness, mt.ior, s2z, s2w);
+    r[3] = s3;
+}
+__global__ __launch_bounds__(256) void k_lbvh_pack_prims(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
+                                                         const uint32_t *ord_s, const uint32_t *ord_q, const uint32_t *ord_t, const kl_material *m,
+                                                         uint32_t n_nodes, float4 *rec, float4 *shrec) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns + nq + nt) return;
+    const float4 zero4 = make_float4(0, 0, 0, 0);
+    float4 *r = rec + 4 * ((size_t)n_nodes + k), *sr = shrec + 4 * (size_t)k;
+    if (k < ns) {
+        const uint32_t i = ord_s[k];
+        const kl_sphere &x = s[i];
+        r[0] = make_float4(x.center[0], x.center[1], x.center[2], x.radius);
+        r[1] = make_float4(__uint_as_float(i), __uint_as_float(x.material), 0.0f, 0.0f);
+        r[2] = zero4; r[3] = zero4;
+        pack_shade(sr, V(x.center[0], x.center[1], x.center[2]), m[x.material], x.radius, 0.0f, zero4);
+    } else if (k < ns + nq) {
+        const uint32_t i = ord_q[k - ns];
+        const kl_quad &x = q[i];
+        const kl_material &mt = m[x.material];
+        r[0] = make_float4(x.v0[0], x.v0[1], x.v0[2], x.v1[0]);
+        r[1] = make_float4(x.v1[1], x.v1[2], x.v2[0], x.v2[1]);
+        r[2] = make_float4(x.v2[2], x.v3[0], x.v3[1], x.v3[2]);
+        r[3] = make_float4(__uint_as_float(ns + i), __uint_as_float(x.material), __uint_as_float(mt.type == KL_TEXTURED ? 1u : 0u), 0.0f);
+        const v3 v1 = V(x.v1[0], x.v1[1], x.v1[2]), v2 = V(x.v2[0], x.v2[1], x.v2[2]), v3_ = V(x.v3[0], x.v3[1], x.v3[2]);
+        pack_shade(sr, normalize(cross(v2 - v1, v3_ - v1)), mt, 0.0f, 0.0f, zero4);          // RawFrame.glsl:319
+    } else {
+        const uint32_t i = ord_t[k - ns - nq];
+        const kl_tri &x = t[i];
+        const kl_material &mt = m[x.material];
+        const v3 v0 = V(x.v0[0], x.v0[1], x.v0[2]);
+        const v3 e1 = V(x.v1[0], x.v1[1], x.v1[2]) - v0, e2 = V(x.v2[0], x.v2[1], x.v2[2]) - v0;
+        const v3 nor = normalize(cross(e1, e2));
+        r[0] = make_float4(v0.x, v0.y, v0.z, e1.x);
+        r[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+        r[2] = make_float4(e2.z, __uint_as_float(ns + nq + i), __uint_as_float(x.material), __uint_as_float(mt.type == KL_TEXTURED ? 1u : 0u));
+        r[3] = zero4;
+        pack_shade(sr, nor, mt, x.uv0[0], x.uv0[1], make_float4(x.uv1[0], x.uv1[1], x.uv2[0], x.uv2[1]));
+    }
+}
+
 struct Buf {
     void *p = nullptr;
     ~Buf() { if (p) (void)hipFree(p); }
@@ -321,7 +384,8 @@ inline uint32_t blocks_for(uint32_t n) { return n ? (n + 255u) / 256u : 1u; }
 }  // namespace
 
 LbvhResult build_bvh_gpu(hipStream_t stream, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq,
-                   const kl_tri *t, uint32_t nt, HostBVH &out, float flat_fraction, uint32_t max_flat, std::string &err) {
+                   const kl_tri *t, uint32_t nt, HostBVH &out, float flat_fraction, uint32_t max_flat, std::string &err,
+                   const kl_material *m, uint32_t nm, GpuScene *packed) {
     const auto t0 = std::chrono::steady_clock::now();
     const uint32_t n = ns + nq + nt;
     identity_order(0, 0, 0, out);
@@ -428,14 +492,38 @@ LbvhResult build_bvh_gpu(hipStream_t stream, const kl_sphere *s, uint32_t ns, co
         count4 = end; root4 = 0;
     }
     LB(hipGetLastError());
-    // results to the host
-    out.nodes4.resize((size_t)count4 * 16);
-    if (count4) LB(hipMemcpyAsync(out.nodes4.data(), d_nodes4.p, (size_t)count4 * 64, hipMemcpyDeviceToHost, stream));
-    out.sph_order.resize(ns); out.quad_order.resize(nq); out.tri_order.resize(nt);
-    if (ns) LB(hipMemcpyAsync(out.sph_order.data(), d_ord[0].p, (size_t)ns * 4, hipMemcpyDeviceToHost, stream));
-    if (nq) LB(hipMemcpyAsync(out.quad_order.data(), d_ord[1].p, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
-    if (nt) LB(hipMemcpyAsync(out.tri_order.data(), d_ord[2].p, (size_t)nt * 4, hipMemcpyDeviceToHost, stream));
-    LB(hipStreamSynchronize(stream));
+    if (packed && m && nm) {
+        // records and shading records written here, from the primitives and orders already on the device
+        Buf d_m, d_rec, d_shrec;
+        const size_t n_rec = std::max<size_t>((size_t)count4 + n, 1), n_shrec = std::max<size_t>(n, 1);
+        LB(d_m.alloc((size_t)nm * sizeof(kl_material)));
+        LB(hipMemcpyAsync(d_m.p, m, (size_t)nm * sizeof(kl_material), hipMemcpyHostToDevice, stream));
+        LB(d_rec.alloc(n_rec * 64)); LB(d_shrec.alloc(n_shrec * 64));
+        if (count4)
+            hipLaunchKernelGGL(k_lbvh_pack_nodes, dim3(blocks_for(count4)), dim3(256), 0, stream, d_nodes4.as<uint32_t>(), count4,
+                               count4, count4 + ns, count4 + ns + nq, d_rec.as<uint4>());
+        hipLaunchKernelGGL(k_lbvh_pack_prims, dim3(blocks_for(n)), dim3(256), 0, stream, d_s.as<kl_sphere>(), ns, d_q.as<kl_quad>(), nq, d_t.as<kl_tri>(), nt,
+                           d_ord[0].as<uint32_t>(), d_ord[1].as<uint32_t>(), d_ord[2].as<uint32_t>(), d_m.as<kl_material>(), count4,
+                           d_rec.as<float4>(), d_shrec.as<float4>());
+        // the flat quads close the quad order: their indices go back for the caller's quad table
+        uint32_t nfq = 0;
+        for (uint32_t g : flat) nfq += (g >= ns && g < ns + nq) ? 1u : 0u;
+        packed->flat_quads.resize(nfq);
+        if (nfq) LB(hipMemcpyAsync(packed->flat_quads.data(), d_ord[1].as<uint32_t>() + (nq - nfq), (size_t)nfq * 4, hipMemcpyDeviceToHost, stream));
+        LB(hipStreamSynchronize(stream));
+        LB(hipGetLastError());
+        packed->d_rec = d_rec.p; packed->n_rec = n_rec; d_rec.p = nullptr;          // ownership passes to the caller
+        packed->d_shrec = d_shrec.p; packed->n_shrec = n_shrec; d_shrec.p = nullptr;
+    } else {
+        // results to the host
+        out.nodes4.resize((size_t)count4 * 16);
+        if (count4) LB(hipMemcpyAsync(out.nodes4.data(), d_nodes4.p, (size_t)count4 * 64, hipMemcpyDeviceToHost, stream));
+        out.sph_order.resize(ns); out.quad_order.resize(nq); out.tri_order.resize(nt);
+        if (ns) LB(hipMemcpyAsync(out.sph_order.data(), d_ord[0].p, (size_t)ns * 4, hipMemcpyDeviceToHost, stream));
+        if (nq) LB(hipMemcpyAsync(out.quad_order.data(), d_ord[1].p, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+        if (nt) LB(hipMemcpyAsync(out.tri_order.data(), d_ord[2].p, (size_t)nt * 4, hipMemcpyDeviceToHost, stream));
+        LB(hipStreamSynchronize(stream));
+    }
 #undef LB
     out.root4 = root4; out.depth4 = depth4;
     // the flat primitives sorted last, so they close each order array

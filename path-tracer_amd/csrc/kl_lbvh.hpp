@@ -5,6 +5,7 @@
 #pragma once
 
 #include <string>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 
@@ -14,12 +15,28 @@ namespace kl {
 
 enum LbvhResult { LBVH_OK = 0, LBVH_TOO_DEEP = 1, LBVH_HIP_ERROR = -1 };
 
-// Builds on `stream`'s device. A leaf holds one primitive, or two that were siblings in the binary tree. LBVH_TOO_DEEP: the tree is deeper than the
-// traversal stack allows (BVH_MAX_DEPTH 4-wide levels; possible when very many primitives share a Morton
-// cell) and the caller builds on the host instead; LBVH_HIP_ERROR: a HIP call failed (`err` says which).
-// Primitives whose box area is at least `flat_fraction` of the scene's (at most `max_flat`, and at most
-// 1024 candidates: beyond that none) stay out of the tree.
+// What build_bvh_gpu hands over when it also packs the scene's records on the device: two hipMalloc'ed arrays
+// of 64-byte records (layout: kl_types.hpp). Whoever takes a pointer out sets it to null here; what is left is freed.
+struct GpuScene {
+    void *d_rec = nullptr; size_t n_rec = 0;           // nodes, then spheres, quads, triangles in leaf order
+    void *d_shrec = nullptr; size_t n_shrec = 0;       // one shading record per primitive, same order
+    std::vector<uint32_t> flat_quads;                  // the flat quads' indices into the caller's quad array, in flat order
+    GpuScene() = default;
+    GpuScene(const GpuScene &) = delete;
+    GpuScene &operator=(const GpuScene &) = delete;
+    ~GpuScene() { if (d_rec) (void)hipFree(d_rec); if (d_shrec) (void)hipFree(d_shrec); }
+};
+
+// Builds on `stream`'s device. A leaf holds one primitive, or two that were siblings in the binary tree.
+// LBVH_TOO_DEEP: the tree is deeper than the traversal stack allows (BVH_MAX_DEPTH 4-wide levels; possible when
+// very many primitives share a Morton cell) and the caller builds on the host instead; LBVH_HIP_ERROR: a HIP
+// call failed (`err` says which). Primitives whose box area is at least `flat_fraction` of the scene's (at most
+// `max_flat`, and at most 1024 candidates: beyond that none) stay out of the tree.
+// With `packed` (and the materials) the builder also writes the record and shading-record arrays on the GPU,
+// from the primitives it has already copied there; `out` then carries only the statistics, the flat ranges and
+// the root (no nodes4, no orders), and nothing but a handful of words returns to the host.
 LbvhResult build_bvh_gpu(hipStream_t stream, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq,
-                   const kl_tri *t, uint32_t nt, HostBVH &out, float flat_fraction, uint32_t max_flat, std::string &err);
+                   const kl_tri *t, uint32_t nt, HostBVH &out, float flat_fraction, uint32_t max_flat, std::string &err,
+                   const kl_material *m = nullptr, uint32_t nm = 0, GpuScene *packed = nullptr);
 
 }  // namespace kl

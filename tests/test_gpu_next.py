@@ -170,6 +170,33 @@ def test_gpu_built_tree_renders_like_the_oracle(textures):
     assert_bitexact(acc, ko.render_mean(sc, ko.default_camera(), p, 3), "GPU-built tree, path traced")
 
 
+def test_records_packed_on_the_gpu_match_the_host_packing(textures, monkeypatch):
+    """The GPU builder writes the scene's records on the device; packed on the host from the same tree
+    (KL_PACK_HOST=1) every pixel of every mode must come out the same, flat quads and textured triangles included."""
+    s, q, t, m = kl.synth_scene(blobs=30, tris_per_blob=200, analytic_spheres=60, seed=11)
+    w, h = 160, 90
+    out = {}
+    for where in ("gpu", "host"):
+        if where == "host":
+            monkeypatch.setenv("KL_PACK_HOST", "1")
+        with kl.Renderer(w, h) as r:
+            r.update_params(bvh_builder=kl.BUILD_GPU_LBVH, max_bounces=8, max_frames=0, accel=kl.ACCEL_BVH)
+            r.upload_scene(s, q, t, m)
+            st = r.bvh_stats()
+            assert st.builder == kl.BUILD_GPU_LBVH
+            r.upload_texture(kl.TEX_HDRI, textures["hdri"]); r.upload_texture(kl.TEX_ALBEDO, textures["albedo"])
+            imgs = []
+            for mode in (kl.MODE_PT, kl.MODE_Z, kl.MODE_AO):
+                r.update_params(mode=mode); r.reset()
+                r.render_frames(4)
+                imgs.append(r.read_accum())
+            out[where] = (imgs, (st.nodes, st.flat_spheres, st.flat_quads, st.flat_tris))
+    assert out["gpu"][1] == out["host"][1]
+    assert out["gpu"][1][2] > 0, "the scene is meant to have flat quads"
+    for a, b, name in zip(out["gpu"][0], out["host"][0], ("path traced", "depth", "ao")):
+        assert_bitexact(a, b, "records packed on the GPU vs on the host: " + name)
+
+
 def test_gpu_build_of_a_million_triangles():
     """BASELINE config 3's scene: the GPU build against the host build on the same rays"""
     from test_gpu_scene import random_rays
