@@ -131,6 +131,7 @@ typedef struct kl_bvh_stats {
     uint64_t node_bytes, prim_bytes;
     uint32_t flat_spheres, flat_quads, flat_tris; /* scene-spanning primitives kept out of the tree and tested for every ray */
     uint32_t builder;          /* KL_BUILD_* that produced the tree in use */
+    double refit_seconds;      /* duration of the last kl_refit_scene, 0 if none since the upload */
 } kl_bvh_stats;
 
 /* parameters of the seed-deterministic synthetic benchmark scene */
@@ -187,6 +188,13 @@ KL_API kl_status kl_load_builtin_scene(kl_ctx *ctx);                    /* RawFr
 KL_API kl_status kl_load_mesh(const char *path, uint32_t material, uint32_t n_materials, kl_tri **tris, uint32_t *n_tris);
 KL_API const char *kl_load_mesh_error(void);
 KL_API void kl_free(void *p);
+/* Moved geometry (no reference counterpart: the shader's scene is compiled in, RawFrame.glsl:171-192). The arrays hold
+ * the primitives of the last kl_upload_scene in the same order, with new positions (and triangle uvs); their material
+ * fields are ignored, materials stay as uploaded. The tree keeps its shape and every box is recomputed on the GPU, so
+ * the result is exact; a tree refitted far from the geometry it was built for is slower, not wrong. The frame counter
+ * goes back to 0 as after any scene change. KL_E_INVALID if the counts differ from the uploaded scene's. */
+KL_API kl_status kl_refit_scene(kl_ctx *ctx, const kl_sphere *spheres, uint32_t n_spheres, const kl_quad *quads, uint32_t n_quads,
+                                const kl_tri *tris, uint32_t n_tris);
 KL_API kl_status kl_get_bvh_stats(kl_ctx *ctx, kl_bvh_stats *out);
 /* synthetic benchmark scene (no reference counterpart): sizes first, then fill caller-owned arrays */
 KL_API kl_status kl_synth_scene_counts(const kl_synth_params *sp, uint32_t *n_spheres, uint32_t *n_quads,

@@ -83,6 +83,9 @@ struct kl_ctx {
     SceneDev sc;
     kl_bvh_stats bvh_stats;
     DevBuf<float4> d_rec, d_shrec, d_flatq;
+    std::vector<float4> h_flatq;            // host copy of the flat-quad table, and which quads it holds (for kl_refit_scene)
+    std::vector<uint32_t> flat_quad_index;
+    int32_t tree_root = NODE_DONE;          // root reference as the builder gave it (a node index, or a leaf)
     DevBuf<uchar4> d_tex[2];
     DevBuf<float4> d_envf;
     // wavefront state
@@ -358,6 +361,26 @@ template <typename T> kl_status upload(kl_ctx *c, DevBuf<T> &buf, const void *sr
     KL_HIP(c, buf.alloc(std::max<size_t>(count, 1)));
     if (count) KL_HIP(c, hipMemcpyAsync(buf.p, src, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
     return KL_OK;
+}
+
+// Ray-independent terms of the quad test (RawFrame.glsl:219-244) for a flat quad, in the test's own operations:
+// F0..F3 of the flat-quad table (kl_types.hpp)
+void flat_quad_terms(const kl_quad &x, float4 *f) {
+    auto bits = [](uint32_t v) { float r; std::memcpy(&r, &v, 4); return r; };
+    v3 v0 = V(x.v0[0], x.v0[1], x.v0[2]);
+    v3 a = V(x.v1[0], x.v1[1], x.v1[2]) - v0, b = V(x.v3[0], x.v3[1], x.v3[2]) - v0, cc = V(x.v2[0], x.v2[1], x.v2[2]) - v0;
+    v3 nor = cross(a, b);
+    v3 mor = V(std::fabs(nor.x), std::fabs(nor.y), std::fabs(nor.z));
+    int id = (mor.x > mor.y && mor.x > mor.z) ? 0 : ((mor.y > mor.z) ? 1 : 2);
+    int idu = id == 0 ? 1 : (id == 1 ? 2 : 0), idv = id == 0 ? 2 : (id == 1 ? 0 : 1);
+    float kax = comp(a, idu), kay = comp(a, idv), kbx = comp(b, idu), kby = comp(b, idv);
+    float kcx = comp(cc, idu), kcy = comp(cc, idv);
+    float kgx = kcx - kbx - kax, kgy = kcy - kby - kay;
+    float k2 = cross2d(kcx - kbx, kcy - kby, kax, kay);
+    f[0] = make_float4(v0.x, v0.y, v0.z, comp(nor, id));
+    f[1] = make_float4(nor.x, nor.y, nor.z, k2);
+    f[2] = make_float4(kax, kay, kbx, kby);
+    f[3] = make_float4(kgx, kgy, bits((uint32_t)idu | ((uint32_t)idv << 2)), 0.0f);
 }
 
 }  // namespace
@@ -640,28 +663,17 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     const int32_t tree_root = bvh.root4;
     bvh.stats.nodes = n_nodes; bvh.stats.max_depth = bvh.depth4; bvh.stats.node_bytes = (uint64_t)n_nodes * 64u;
     bvh.stats.builder = builder;
-    // ray-independent terms of the quad test (RawFrame.glsl:219-244) for the flat quads, in the test's own operations
+    // the flat quads' table
     const uint32_t nfq = bvh.flat_count[PRIM_QUAD];
     std::vector<float4> flatq((size_t)nfq * 5);
+    c->flat_quad_index.resize(nfq);
     for (uint32_t k = 0; k < nfq; k++) {
         const uint32_t qi = on_gpu ? packed.flat_quads[k] : bvh.quad_order[bvh.flat_start[PRIM_QUAD] + k];
-        const kl_quad &x = q[qi];
-        v3 v0 = V(x.v0[0], x.v0[1], x.v0[2]);
-        v3 a = V(x.v1[0], x.v1[1], x.v1[2]) - v0, b = V(x.v3[0], x.v3[1], x.v3[2]) - v0, cc = V(x.v2[0], x.v2[1], x.v2[2]) - v0;
-        v3 nor = cross(a, b);
-        v3 mor = V(std::fabs(nor.x), std::fabs(nor.y), std::fabs(nor.z));
-        int id = (mor.x > mor.y && mor.x > mor.z) ? 0 : ((mor.y > mor.z) ? 1 : 2);
-        int idu = id == 0 ? 1 : (id == 1 ? 2 : 0), idv = id == 0 ? 2 : (id == 1 ? 0 : 1);
-        float kax = comp(a, idu), kay = comp(a, idv), kbx = comp(b, idu), kby = comp(b, idv);
-        float kcx = comp(cc, idu), kcy = comp(cc, idv);
-        float kgx = kcx - kbx - kax, kgy = kcy - kby - kay;
-        float k2 = cross2d(kcx - kbx, kcy - kby, kax, kay);
-        flatq[5 * (size_t)k] = make_float4(v0.x, v0.y, v0.z, comp(nor, id));
-        flatq[5 * (size_t)k + 1] = make_float4(nor.x, nor.y, nor.z, k2);
-        flatq[5 * (size_t)k + 2] = make_float4(kax, kay, kbx, kby);
-        flatq[5 * (size_t)k + 3] = make_float4(kgx, kgy, bits((uint32_t)idu | ((uint32_t)idv << 2)), 0.0f);
-        flatq[5 * (size_t)k + 4] = make_float4(bits(ns + qi), bits(m[x.material].type == KL_TEXTURED ? 1u : 0u), 0.0f, 0.0f);
+        c->flat_quad_index[k] = qi;
+        flat_quad_terms(q[qi], &flatq[5 * (size_t)k]);
+        flatq[5 * (size_t)k + 4] = make_float4(bits(ns + qi), bits(m[q[qi].material].type == KL_TEXTURED ? 1u : 0u), 0.0f, 0.0f);
     }
+    c->h_flatq = flatq;
     kl_status st;
     if ((st = upload(c, c->d_flatq, flatq.data(), flatq.size())) != KL_OK) return st;
     if (on_gpu) {                                    // the builder's buffers become the scene's
@@ -672,7 +684,7 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
         if ((st = upload(c, c->d_shrec, shrec.get(), n_shrec * 4)) != KL_OK) return st;
     }
     KL_HIP(c, hipStreamSynchronize(c->stream));     // the host vectors go out of scope below
-    c->sc.rec = c->d_rec.p; c->sc.root = patch_child(tree_root); c->sc.n_nodes = n_nodes;
+    c->sc.rec = c->d_rec.p; c->sc.root = patch_child(tree_root); c->sc.n_nodes = n_nodes; c->tree_root = tree_root;
     c->sc.shrec = c->d_shrec.p; c->sc.flatq = c->d_flatq.p;
     c->sc.count[PRIM_SPHERE] = ns; c->sc.count[PRIM_QUAD] = nq; c->sc.count[PRIM_TRI] = nt;
     for (int k = 0; k < 3; k++) {
@@ -681,6 +693,7 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     }
     c->n_prims = ns + nq + nt;
     c->bvh_stats = bvh.stats;
+    c->bvh_stats.refit_seconds = 0.0;
     c->bvh_stats.prim_bytes = ((uint64_t)ns + nq + nt) * 64;
     c->bvh_stats.flat_spheres = bvh.flat_count[PRIM_SPHERE]; c->bvh_stats.flat_quads = bvh.flat_count[PRIM_QUAD];
     c->bvh_stats.flat_tris = bvh.flat_count[PRIM_TRI];
@@ -693,6 +706,25 @@ kl_status kl_load_builtin_scene(kl_ctx *c) {
     std::vector<kl_sphere> s; std::vector<kl_quad> q; std::vector<kl_material> m;
     builtin_scene(s, q, m);
     return kl_upload_scene(c, s.data(), (uint32_t)s.size(), q.data(), (uint32_t)q.size(), nullptr, 0, m.data(), (uint32_t)m.size());
+}
+kl_status kl_refit_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt) {
+    if (!c || (ns && !s) || (nq && !q) || (nt && !t)) return fail(c, KL_E_INVALID, "null scene array");
+    if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");
+    if (ns != c->sc.count[PRIM_SPHERE] || nq != c->sc.count[PRIM_QUAD] || nt != c->sc.count[PRIM_TRI])
+        return fail(c, KL_E_INVALID, "refit needs the primitive counts of the uploaded scene");
+    KL_HIP(c, hipSetDevice(c->device));
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    std::string why;
+    if (refit_scene_gpu(c->stream, c->d_rec.p, c->d_shrec.p, c->sc.n_nodes, c->tree_root, (uint32_t)BVH_MAX_DEPTH + 1u, s, ns, q, nq, t, nt, why) != LBVH_OK)
+        return fail(c, KL_E_DEVICE, "refit: " + why);
+    for (size_t k = 0; k < c->flat_quad_index.size(); k++) flat_quad_terms(q[c->flat_quad_index[k]], &c->h_flatq[5 * k]);
+    if (!c->h_flatq.empty()) {
+        KL_HIP(c, hipMemcpyAsync(c->d_flatq.p, c->h_flatq.data(), c->h_flatq.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        KL_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->bvh_stats.refit_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return kl_reset(c);
 }
 kl_status kl_get_bvh_stats(kl_ctx *c, kl_bvh_stats *out) {
     if (!c || !out) return KL_E_INVALID;

@@ -192,32 +192,11 @@ void collapse_node(const HostBVH &bvh, int32_t node2, uint32_t idx, std::vector<
         ch.push_back(child_of(open, 1));
     }
     max_depth = std::max(max_depth, depth);
-    Box nb; nb.reset();
-    for (const Child4 &c : ch) nb.grow(c.box);
     uint32_t w[16]; std::memset(w, 0, sizeof w);
-    double scale[3];
-    for (int a = 0; a < 3; a++) {
-        std::memcpy(&w[a], &nb.lo[a], 4);
-        double ext = (double)nb.hi[a] - (double)nb.lo[a];
-        int e = ext > 0.0 ? (int)std::ceil(std::log2(ext / 255.0)) : -100;
-        if (e < -100) e = -100;
-        while (std::ldexp(255.0, e) < ext) e++;          // guard the rounding of log2
-        scale[a] = std::ldexp(1.0, e);
-        const float step = (float)scale[a];              // a power of two: exact
-        std::memcpy(&w[3 + a], &step, 4);
-    }
-    for (int k = 0; k < 4; k++) {
-        uint32_t qlo[3] = {255, 255, 255}, qhi[3] = {0, 0, 0};     // empty slot: inverted box, never entered
-        if (k < (int)ch.size()) {
-            for (int a = 0; a < 3; a++) {
-                double l = std::floor(((double)ch[k].box.lo[a] - (double)nb.lo[a]) / scale[a]);
-                double h = std::ceil(((double)ch[k].box.hi[a] - (double)nb.lo[a]) / scale[a]);
-                qlo[a] = (uint32_t)std::min(255.0, std::max(0.0, l));
-                qhi[a] = (uint32_t)std::min(255.0, std::max(0.0, h));
-            }
-        }
-        for (int a = 0; a < 3; a++) { w[6 + a] |= qlo[a] << (8 * k); w[9 + a] |= qhi[a] << (8 * k); }
-    }
+    float boxes[4][6];
+    for (size_t k = 0; k < ch.size(); k++)
+        for (int a = 0; a < 3; a++) { boxes[k][a] = ch[k].box.lo[a]; boxes[k][3 + a] = ch[k].box.hi[a]; }
+    node4_boxes(&boxes[0][0], (int)ch.size(), w);
     uint32_t next = (uint32_t)(out.size() / 16);           // inner children: consecutive indices from here
     uint32_t n_inner = 0;
     for (const Child4 &c : ch) n_inner += c.ref >= 0 ? 1u : 0u;

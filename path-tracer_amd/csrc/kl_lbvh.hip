@@ -45,6 +45,28 @@ __device__ __forceinline__ void grow(float lo[3], float hi[3], const float p[3])
     for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], p[k]); hi[k] = fmaxf(hi[k], p[k]); }
 }
 
+// Boxes of the primitives, widened by a few ulps like the host builder's leaves: rounding in the slab test must
+// not cull a primitive that exact arithmetic would reach. lo / hi come in as +inf / -inf.
+__device__ __forceinline__ void pad_box(float lo[3], float hi[3]) {
+    for (int k = 0; k < 3; k++) {
+        const float m = fmaxf(fabsf(lo[k]), fabsf(hi[k]));
+        const float pad = 1e-6f + 4e-6f * m;
+        lo[k] -= pad; hi[k] += pad;
+    }
+}
+__device__ __forceinline__ void sphere_box(const kl_sphere &x, float lo[3], float hi[3]) {
+    for (int k = 0; k < 3; k++) { lo[k] = x.center[k] - x.radius; hi[k] = x.center[k] + x.radius; }
+    pad_box(lo, hi);
+}
+__device__ __forceinline__ void quad_box(const kl_quad &x, float lo[3], float hi[3]) {
+    grow(lo, hi, x.v0); grow(lo, hi, x.v1); grow(lo, hi, x.v2); grow(lo, hi, x.v3);
+    pad_box(lo, hi);
+}
+__device__ __forceinline__ void tri_box(const kl_tri &x, float lo[3], float hi[3]) {
+    grow(lo, hi, x.v0); grow(lo, hi, x.v1); grow(lo, hi, x.v2);
+    pad_box(lo, hi);
+}
+
 __global__ __launch_bounds__(256) void k_lbvh_bounds(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
                                                      float4 *blo, float4 *bhi, uint32_t *scene) {
     const uint32_t n = ns + nq + nt;
@@ -52,22 +74,9 @@ __global__ __launch_bounds__(256) void k_lbvh_bounds(const kl_sphere *s, uint32_
     const float inf = __builtin_huge_valf();
     float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
     if (g < n) {
-        if (g < ns) {
-            for (int k = 0; k < 3; k++) { lo[k] = s[g].center[k] - s[g].radius; hi[k] = s[g].center[k] + s[g].radius; }
-        } else if (g < ns + nq) {
-            const kl_quad &x = q[g - ns];
-            grow(lo, hi, x.v0); grow(lo, hi, x.v1); grow(lo, hi, x.v2); grow(lo, hi, x.v3);
-        } else {
-            const kl_tri &x = t[g - ns - nq];
-            grow(lo, hi, x.v0); grow(lo, hi, x.v1); grow(lo, hi, x.v2);
-        }
-        // widened by a few ulps, like the host builder's leaves: rounding in the slab test must not cull a
-        // primitive that exact arithmetic would reach
-        for (int k = 0; k < 3; k++) {
-            const float m = fmaxf(fabsf(lo[k]), fabsf(hi[k]));
-            const float pad = 1e-6f + 4e-6f * m;
-            lo[k] -= pad; hi[k] += pad;
-        }
+        if (g < ns) sphere_box(s[g], lo, hi);
+        else if (g < ns + nq) quad_box(q[g - ns], lo, hi);
+        else tri_box(t[g - ns - nq], lo, hi);
         const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
         const float area = (dx < 0 || dy < 0 || dz < 0) ? 0.0f : 2.0f * (dx * dy + dy * dz + dz * dx);
         blo[g] = make_float4(lo[0], lo[1], lo[2], area);
@@ -269,34 +278,9 @@ __global__ __launch_bounds__(256) void k_lbvh_collapse(uint32_t begin, uint32_t 
         child(right[open], nch);
         nch++;
     }
-    float nlo[3], nhi[3];
-    for (int a = 0; a < 3; a++) {
-        nlo[a] = box[0].lo[a]; nhi[a] = box[0].hi[a];
-        for (int k = 1; k < nch; k++) { nlo[a] = fminf(nlo[a], box[k].lo[a]); nhi[a] = fmaxf(nhi[a], box[k].hi[a]); }
-    }
     uint32_t w[16];
-    for (int k = 0; k < 16; k++) w[k] = 0u;
-    double scale[3];
-    for (int a = 0; a < 3; a++) {
-        w[a] = __float_as_uint(nlo[a]);
-        const double ext = (double)nhi[a] - (double)nlo[a];
-        int e = ext > 0.0 ? (int)ceil(log2(ext / 255.0)) : -100;
-        if (e < -100) e = -100;
-        while (ldexp(255.0, e) < ext) e++;               // guard the rounding of log2
-        scale[a] = ldexp(1.0, e);
-        w[3 + a] = __float_as_uint((float)scale[a]);     // a power of two: exact
-    }
-    for (int k = 0; k < 4; k++) {
-        uint32_t qlo[3] = { 255u, 255u, 255u }, qhi[3] = { 0u, 0u, 0u };   // empty slot: inverted box, never entered
-        if (k < nch)
-            for (int a = 0; a < 3; a++) {
-                const double l = floor(((double)box[k].lo[a] - (double)nlo[a]) / scale[a]);
-                const double h = ceil(((double)box[k].hi[a] - (double)nlo[a]) / scale[a]);
-                qlo[a] = (uint32_t)fmin(255.0, fmax(0.0, l));
-                qhi[a] = (uint32_t)fmin(255.0, fmax(0.0, h));
-            }
-        for (int a = 0; a < 3; a++) { w[6 + a] |= qlo[a] << (8 * k); w[9 + a] |= qhi[a] << (8 * k); }
-    }
+    static_assert(sizeof(CBox) == 24, "node4_boxes reads the boxes as 6 floats each");
+    node4_boxes(&box[0].lo[0], nch, w);
     uint32_t n_inner = 0;
     for (int k = 0; k < nch; k++) n_inner += ref[k] >= 0 ? 1u : 0u;
     uint32_t next = n_inner ? atomicAdd(alloc, n_inner) : 0u;
@@ -370,6 +354,114 @@ __global__ __launch_bounds__(256) void k_lbvh_pack_prims(const kl_sphere *s, uin
         r[3] = zero4;
         pack_shade(sr, nor, mt, x.uv0[0], x.uv0[1], make_float4(x.uv1[0], x.uv1[1], x.uv2[0], x.uv2[1]));
     }
+}
+
+// ---- refit: the uploaded tree kept, every box recomputed from moved primitives -------------------------------
+// New geometry into the records and shading records of the primitives, each found through the id its record
+// carries; ids, materials and uv flags stay. plo / phi = the primitives' boxes in record order.
+__global__ __launch_bounds__(256) void k_refit_prims(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
+                                                     uint32_t n_nodes, float4 *rec, float4 *shrec, float4 *plo, float4 *phi) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns + nq + nt) return;
+    float4 *r = rec + 4 * ((size_t)n_nodes + k), *sr = shrec + 4 * (size_t)k;
+    const float inf = __builtin_huge_valf();
+    float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+    if (k < ns) {
+        const uint32_t i = __float_as_uint(r[1].x);
+        if (i < ns) {
+            const kl_sphere &x = s[i];
+            r[0] = make_float4(x.center[0], x.center[1], x.center[2], x.radius);
+            sr[0] = make_float4(x.center[0], x.center[1], x.center[2], sr[0].w);
+            sr[2].z = x.radius;
+            sphere_box(x, lo, hi);
+        }
+    } else if (k < ns + nq) {
+        const float4 tail = r[3];
+        const uint32_t i = __float_as_uint(tail.x) - ns;
+        if (i < nq) {
+            const kl_quad &x = q[i];
+            r[0] = make_float4(x.v0[0], x.v0[1], x.v0[2], x.v1[0]);
+            r[1] = make_float4(x.v1[1], x.v1[2], x.v2[0], x.v2[1]);
+            r[2] = make_float4(x.v2[2], x.v3[0], x.v3[1], x.v3[2]);
+            const v3 v1 = V(x.v1[0], x.v1[1], x.v1[2]), v2 = V(x.v2[0], x.v2[1], x.v2[2]), v3_ = V(x.v3[0], x.v3[1], x.v3[2]);
+            const v3 nor = normalize(cross(v2 - v1, v3_ - v1));          // RawFrame.glsl:319
+            sr[0] = make_float4(nor.x, nor.y, nor.z, sr[0].w);
+            quad_box(x, lo, hi);
+        }
+    } else {
+        const float4 q2 = r[2];
+        const uint32_t i = __float_as_uint(q2.y) - ns - nq;
+        if (i < nt) {
+            const kl_tri &x = t[i];
+            const v3 v0 = V(x.v0[0], x.v0[1], x.v0[2]);
+            const v3 e1 = V(x.v1[0], x.v1[1], x.v1[2]) - v0, e2 = V(x.v2[0], x.v2[1], x.v2[2]) - v0;
+            const v3 nor = normalize(cross(e1, e2));
+            r[0] = make_float4(v0.x, v0.y, v0.z, e1.x);
+            r[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+            r[2] = make_float4(e2.z, q2.y, q2.z, q2.w);
+            sr[0] = make_float4(nor.x, nor.y, nor.z, sr[0].w);
+            const float4 s2 = sr[2];
+            sr[2] = make_float4(s2.x, s2.y, x.uv0[0], x.uv0[1]);
+            sr[3] = make_float4(x.uv1[0], x.uv1[1], x.uv2[0], x.uv2[1]);
+            tri_box(x, lo, hi);
+        }
+    }
+    plo[k] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    phi[k] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+}
+__device__ __forceinline__ bool slot_empty(const uint4 &b, const uint4 &c, int k) {          // w6 = b.z (lo.x bytes), w9 = c.y (hi.x bytes)
+    return ((b.z >> (8 * k)) & 255u) > ((c.y >> (8 * k)) & 255u);
+}
+// level of every node below the root, one launch per level from the root down
+__global__ __launch_bounds__(256) void k_refit_levels(uint32_t level, uint32_t n_nodes, const uint4 *rec, uint32_t *levels) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes || levels[i] != level) return;
+    const uint4 b = rec[4 * (size_t)i + 1], c = rec[4 * (size_t)i + 2], d = rec[4 * (size_t)i + 3];
+    const uint32_t ref[4] = { d.x, d.y, d.z, d.w };
+    for (int k = 0; k < 4; k++)
+        if (!slot_empty(b, c, k) && (int32_t)ref[k] >= 0 && ref[k] < n_nodes) levels[ref[k]] = level + 1u;
+}
+// boxes of the nodes of one level, from the deepest level up: children's boxes come from earlier launches
+__global__ __launch_bounds__(256) void k_refit_nodes(uint32_t level, uint32_t n_nodes, uint32_t n_prims, const uint32_t *levels, uint4 *rec,
+                                                     const float4 *plo, const float4 *phi, float4 *nlo, float4 *nhi) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes || levels[i] != level) return;
+    uint4 *node = rec + 4 * (size_t)i;
+    const uint4 b = node[1], c = node[2], d = node[3];
+    const uint32_t ref[4] = { d.x, d.y, d.z, d.w };
+    const float inf = __builtin_huge_valf();
+    float boxes[4][6];
+    int nch = 0;
+    for (int k = 0; k < 4; k++) {
+        if (slot_empty(b, c, k)) break;                   // empty slots close the node
+        float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+        if ((int32_t)ref[k] >= 0) {
+            if (ref[k] < n_nodes) {
+                const float4 a = nlo[ref[k]], z = nhi[ref[k]];
+                lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; hi[0] = z.x; hi[1] = z.y; hi[2] = z.z;
+            }
+        } else {
+            const uint32_t lv = ~ref[k], cnt = ((lv >> 26) & 7u) + 1u, start = (lv & 0x3FFFFFFu) - n_nodes;
+            for (uint32_t p = start; p < start + cnt && p < n_prims; p++) {
+                const float4 a = plo[p], z = phi[p];
+                lo[0] = fminf(lo[0], a.x); lo[1] = fminf(lo[1], a.y); lo[2] = fminf(lo[2], a.z);
+                hi[0] = fmaxf(hi[0], z.x); hi[1] = fmaxf(hi[1], z.y); hi[2] = fmaxf(hi[2], z.z);
+            }
+        }
+        for (int a = 0; a < 3; a++) { boxes[nch][a] = lo[a]; boxes[nch][3 + a] = hi[a]; }
+        nch++;
+    }
+    if (nch == 0) return;
+    uint32_t w[12];
+    node4_boxes(&boxes[0][0], nch, w);
+    node[0] = make_uint4(w[0], w[1], w[2], w[3]); node[1] = make_uint4(w[4], w[5], w[6], w[7]); node[2] = make_uint4(w[8], w[9], w[10], w[11]);
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; a++) {
+        lo[a] = boxes[0][a]; hi[a] = boxes[0][3 + a];
+        for (int k = 1; k < nch; k++) { lo[a] = fminf(lo[a], boxes[k][a]); hi[a] = fmaxf(hi[a], boxes[k][3 + a]); }
+    }
+    nlo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    nhi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
 }
 
 struct Buf {
@@ -535,6 +627,36 @@ LbvhResult build_bvh_gpu(hipStream_t stream, const kl_sphere *s, uint32_t ns, co
     out.stats.sah_cost = 0.0f;
     out.stats.node_bytes = (uint64_t)count4 * 64u;
     out.stats.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return LBVH_OK;
+}
+
+LbvhResult refit_scene_gpu(hipStream_t stream, float4 *rec, float4 *shrec, uint32_t n_nodes, int32_t root, uint32_t levels,
+                           const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt, std::string &err) {
+    const uint32_t n = ns + nq + nt;
+    if (n == 0) return LBVH_OK;
+    hipError_t e = hipSuccess;
+#define LB(call) do { e = (call); if (e != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e); return LBVH_HIP_ERROR; } } while (0)
+    Buf d_s, d_q, d_t, d_plo, d_phi, d_nlo, d_nhi, d_lev;
+    LB(d_s.alloc((size_t)ns * sizeof(kl_sphere))); LB(d_q.alloc((size_t)nq * sizeof(kl_quad))); LB(d_t.alloc((size_t)nt * sizeof(kl_tri)));
+    if (ns) LB(hipMemcpyAsync(d_s.p, s, (size_t)ns * sizeof(kl_sphere), hipMemcpyHostToDevice, stream));
+    if (nq) LB(hipMemcpyAsync(d_q.p, q, (size_t)nq * sizeof(kl_quad), hipMemcpyHostToDevice, stream));
+    if (nt) LB(hipMemcpyAsync(d_t.p, t, (size_t)nt * sizeof(kl_tri), hipMemcpyHostToDevice, stream));
+    LB(d_plo.alloc((size_t)n * 16)); LB(d_phi.alloc((size_t)n * 16));
+    hipLaunchKernelGGL(k_refit_prims, dim3(blocks_for(n)), dim3(256), 0, stream, d_s.as<kl_sphere>(), ns, d_q.as<kl_quad>(), nq, d_t.as<kl_tri>(), nt,
+                       n_nodes, rec, shrec, d_plo.as<float4>(), d_phi.as<float4>());
+    if (n_nodes && root >= 0 && (uint32_t)root < n_nodes) {
+        LB(d_nlo.alloc((size_t)n_nodes * 16)); LB(d_nhi.alloc((size_t)n_nodes * 16)); LB(d_lev.alloc((size_t)n_nodes * 4));
+        LB(hipMemsetAsync(d_lev.p, 0xFF, (size_t)n_nodes * 4, stream));
+        LB(hipMemsetAsync(d_lev.as<uint32_t>() + root, 0, 4, stream));
+        for (uint32_t l = 0; l + 1 < levels; l++)
+            hipLaunchKernelGGL(k_refit_levels, dim3(blocks_for(n_nodes)), dim3(256), 0, stream, l, n_nodes, (const uint4 *)rec, d_lev.as<uint32_t>());
+        for (uint32_t l = levels; l-- > 0;)
+            hipLaunchKernelGGL(k_refit_nodes, dim3(blocks_for(n_nodes)), dim3(256), 0, stream, l, n_nodes, n, d_lev.as<uint32_t>(), (uint4 *)rec,
+                               d_plo.as<float4>(), d_phi.as<float4>(), d_nlo.as<float4>(), d_nhi.as<float4>());
+    }
+    LB(hipStreamSynchronize(stream));
+    LB(hipGetLastError());
+#undef LB
     return LBVH_OK;
 }
 

@@ -1,4 +1,4 @@
-// GPU-side BVH builder (no reference counterpart): Morton-ordered LBVH, refit, collapse into the 4-wide
+// GPU-side BVH builder and refit (no reference counterpart): Morton-ordered LBVH, refit, collapse into the 4-wide
 // quantised nodes of kl_types.hpp. Same output contract as the host builder (kl_bvh.hpp): it fills the
 // 4-wide part of HostBVH (nodes4, root4, depth4), the per-type leaf orders and the flat-primitive ranges, so
 // everything downstream of the builder (record packing, traversal) is the same code for both.
@@ -38,5 +38,13 @@ struct GpuScene {
 LbvhResult build_bvh_gpu(hipStream_t stream, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq,
                    const kl_tri *t, uint32_t nt, HostBVH &out, float flat_fraction, uint32_t max_flat, std::string &err,
                    const kl_material *m = nullptr, uint32_t nm = 0, GpuScene *packed = nullptr);
+
+// Refit: the tree of an uploaded scene kept as it is, every box recomputed for primitives that have moved. `rec` /
+// `shrec` are the scene's record arrays on the device (n_nodes nodes first), `root` its root reference, `levels`
+// the number of node levels (the build's max_depth). The new arrays hold the same primitives in the same order as
+// at upload; their geometry (and the triangles' uvs) replaces the old, materials stay. One launch per level down
+// (which level each node is on) and one per level up (boxes), all on `stream`; returns when they are done.
+LbvhResult refit_scene_gpu(hipStream_t stream, float4 *rec, float4 *shrec, uint32_t n_nodes, int32_t root, uint32_t levels,
+                           const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt, std::string &err);
 
 }  // namespace kl

@@ -3,7 +3,9 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 namespace kl {
 
@@ -52,6 +54,38 @@ constexpr uint32_t MAX_RECORDS = 1u << 26;  // nodes + primitives
 //   child box = lo + byte * step, rounded outwards at build time. An empty slot holds an inverted box
 //   (lo bytes 255, hi bytes 0), which no ray enters, and repeats the reference of child 0 so that it is a
 //   valid reference whatever rounding does to the box test.
+// Words w0..w11 of a 4-wide node from its children's boxes: `boxes` = nch x 6 floats (lo.xyz, hi.xyz), nch = 1..4;
+// the other slots become empty. Host and device builders and the refit all quantise through this one function.
+__host__ __device__ inline void node4_boxes(const float *boxes, int nch, uint32_t w[12]) {
+    float nlo[3], nhi[3];
+    for (int a = 0; a < 3; a++) {
+        nlo[a] = boxes[a]; nhi[a] = boxes[3 + a];
+        for (int k = 1; k < nch; k++) { nlo[a] = fminf(nlo[a], boxes[6 * k + a]); nhi[a] = fmaxf(nhi[a], boxes[6 * k + 3 + a]); }
+    }
+    for (int k = 0; k < 12; k++) w[k] = 0u;
+    double scale[3];
+    for (int a = 0; a < 3; a++) {
+        memcpy(&w[a], &nlo[a], 4);
+        const double ext = (double)nhi[a] - (double)nlo[a];
+        int e = ext > 0.0 ? (int)ceil(log2(ext / 255.0)) : -100;
+        if (e < -100) e = -100;
+        while (ldexp(255.0, e) < ext) e++;               // guard the rounding of log2
+        scale[a] = ldexp(1.0, e);
+        const float step = (float)scale[a];              // a power of two: exact
+        memcpy(&w[3 + a], &step, 4);
+    }
+    for (int k = 0; k < 4; k++) {
+        uint32_t qlo[3] = { 255u, 255u, 255u }, qhi[3] = { 0u, 0u, 0u };   // empty slot: inverted box, never entered
+        if (k < nch)
+            for (int a = 0; a < 3; a++) {
+                const double l = floor(((double)boxes[6 * k + a] - (double)nlo[a]) / scale[a]);
+                const double h = ceil(((double)boxes[6 * k + 3 + a] - (double)nlo[a]) / scale[a]);
+                qlo[a] = (uint32_t)fmin(255.0, fmax(0.0, l));
+                qhi[a] = (uint32_t)fmin(255.0, fmax(0.0, h));
+            }
+        for (int a = 0; a < 3; a++) { w[6 + a] |= qlo[a] << (8 * k); w[9 + a] |= qhi[a] << (8 * k); }
+    }
+}
 #ifndef KL_BVH_MAX_DEPTH
 #define KL_BVH_MAX_DEPTH 32
 #endif

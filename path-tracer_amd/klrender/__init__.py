@@ -60,7 +60,8 @@ class BvhStats(C.Structure):
     _fields_ = [("nodes", C.c_uint32), ("leaves", C.c_uint32), ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32),
                 ("spheres", C.c_uint32), ("quads", C.c_uint32), ("tris", C.c_uint32), ("sah_cost", C.c_float),
                 ("build_seconds", C.c_double), ("node_bytes", C.c_uint64), ("prim_bytes", C.c_uint64),
-                ("flat_spheres", C.c_uint32), ("flat_quads", C.c_uint32), ("flat_tris", C.c_uint32), ("builder", C.c_uint32)]
+                ("flat_spheres", C.c_uint32), ("flat_quads", C.c_uint32), ("flat_tris", C.c_uint32), ("builder", C.c_uint32),
+                ("refit_seconds", C.c_double)]
 
 
 class SynthParams(C.Structure):
@@ -85,6 +86,7 @@ SIGNATURES = {
     "kl_upload_texture": (C.c_int32, [_P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "kl_upload_scene": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32]),
     "kl_load_builtin_scene": (C.c_int32, [_P]),
+    "kl_refit_scene": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32]),
     "kl_get_bvh_stats": (C.c_int32, [_P, C.POINTER(BvhStats)]),
     "kl_synth_scene_counts": (C.c_int32, [C.POINTER(SynthParams)] + [C.POINTER(C.c_uint32)] * 4),
     "kl_synth_scene_fill": (C.c_int32, [C.POINTER(SynthParams), _P, _P, _P, _P]),
@@ -268,6 +270,13 @@ class Renderer:
             return np.ascontiguousarray(a, dtype=dt) if a is not None else np.zeros(0, dtype=dt)
         s, q, t, m = arr(spheres, sphere_dtype), arr(quads, quad_dtype), arr(tris, tri_dtype), arr(materials, material_dtype)
         self._ck(lib().kl_upload_scene(self._h, _ptr(s), len(s), _ptr(q), len(q), _ptr(t), len(t), _ptr(m), len(m)), "kl_upload_scene")
+
+    def refit_scene(self, spheres=None, quads=None, tris=None):
+        """The uploaded scene's primitives, moved: same counts and order; the tree keeps its shape (kl_refit_scene)."""
+        def arr(a, dt):
+            return np.ascontiguousarray(a, dtype=dt) if a is not None else np.zeros(0, dtype=dt)
+        s, q, t = arr(spheres, sphere_dtype), arr(quads, quad_dtype), arr(tris, tri_dtype)
+        self._ck(lib().kl_refit_scene(self._h, _ptr(s), len(s), _ptr(q), len(q), _ptr(t), len(t)), "kl_refit_scene")
 
     def load_builtin_scene(self):
         self._ck(lib().kl_load_builtin_scene(self._h), "kl_load_builtin_scene")

@@ -217,3 +217,108 @@ def test_gpu_build_of_a_million_triangles():
     assert_bitexact(tg, th, "1M triangles: GPU-built vs host-built tree, t"); assert_bitexact(ug, uh, "uv")
     print("build of 1M triangles: GPU %.4f s, host %.4f s" % (gpu_seconds, host_seconds))
     assert gpu_seconds < host_seconds
+
+
+# ---------------------------------------------------------------- refit
+def _moved(s, q, t, seed):
+    """the same primitives somewhere else: an affine map of everything (quads stay planar), every blob vertex
+    jittered on top, spheres resized"""
+    rng = np.random.default_rng(seed)
+    A = (np.eye(3) + 0.06 * rng.standard_normal((3, 3))).astype(np.float32)
+    b = np.array([0.05, -0.03, 0.1], dtype=np.float32)
+    s2, q2, t2 = s.copy(), q.copy(), t.copy()
+    s2["center"] = s["center"] @ A.T + b
+    s2["radius"] = s["radius"] * rng.uniform(0.7, 1.4, len(s)).astype(np.float32)
+    for v in ("v0", "v1", "v2", "v3"):
+        q2[v] = q[v] @ A.T + b
+    for v in ("v0", "v1", "v2"):
+        t2[v] = t[v] @ A.T + b + rng.uniform(-0.01, 0.01, (len(t), 3)).astype(np.float32)
+    for v in ("uv0", "uv1", "uv2"):
+        t2[v] = (t[v] * 0.9 + 0.05).astype(np.float32)
+    return s2, q2, t2
+
+
+@pytest.mark.parametrize("builder", [kl.BUILD_HOST_SAH, kl.BUILD_GPU_LBVH])
+def test_refit_finds_the_hits_of_a_fresh_upload(builder):
+    """kl_refit_scene keeps the tree and recomputes its boxes: every ray then finds what it finds in a tree built
+    for the moved scene and what the flat loop finds, bit for bit"""
+    from test_gpu_scene import random_rays
+    s, q, t, m = kl.synth_scene(blobs=24, tris_per_blob=160, analytic_spheres=40, seed=3)
+    s2, q2, t2 = _moved(s, q, t, 5)
+    o, d = random_rays(4000, 17)
+    o[:60] = t2["v0"][:60]
+    with kl.Renderer(8, 8) as r:
+        r.update_params(bvh_builder=builder)
+        r.upload_scene(s, q, t, m)
+        before = r.bvh_stats()
+        assert before.refit_seconds == 0.0
+        r.refit_scene(s2, q2, t2)
+        after = r.bvh_stats()
+        assert after.refit_seconds > 0.0 and (after.nodes, after.leaves, after.flat_quads) == (before.nodes, before.leaves, before.flat_quads)
+        (tb, pb, ub), (tf, pf, uf) = _trace_both(r, o, d)
+        r.update_params(accel=kl.ACCEL_BVH)
+        r.upload_scene(s2, q2, t2, m)
+        tn, pn, un = r.trace_rays(o, d)
+        assert r.bvh_stats().refit_seconds == 0.0
+        # and back again: the refit must not depend on what the boxes held before
+        r.refit_scene(s, q, t)
+        t0, p0, u0 = r.trace_rays(o, d)
+        r.upload_scene(s, q, t, m)
+        t1, p1, u1 = r.trace_rays(o, d)
+    assert (pf != kl.MISS).mean() > 0.9
+    assert np.array_equal(pb, pf) and np.array_equal(pb, pn)
+    assert_bitexact(tb, tf, "refitted tree vs flat loop: t"); assert_bitexact(ub, uf, "refitted tree vs flat loop: uv")
+    assert_bitexact(tb, tn, "refitted tree vs fresh tree: t"); assert_bitexact(ub, un, "refitted tree vs fresh tree: uv")
+    assert np.array_equal(p0, p1)
+    assert_bitexact(t0, t1, "refitted back vs fresh: t"); assert_bitexact(u0, u1, "refitted back vs fresh: uv")
+
+
+def test_refit_renders_like_the_oracle(textures):
+    s, q, t, m = kl.synth_scene(blobs=24, tris_per_blob=160, analytic_spheres=40, seed=3)
+    s2, q2, t2 = _moved(s, q, t, 9)
+    w, h = 128, 72
+    with kl.Renderer(w, h) as r:
+        r.update_params(max_bounces=8, max_frames=0, accel=kl.ACCEL_BVH)
+        r.upload_scene(s, q, t, m)
+        r.upload_texture(kl.TEX_HDRI, textures["hdri"]); r.upload_texture(kl.TEX_ALBEDO, textures["albedo"])
+        r.render_frames(2)
+        r.refit_scene(s2, q2, t2)
+        assert r.frame == 0                       # a scene change restarts the accumulation
+        r.render_frames(3)
+        acc = r.read_accum()
+    sc = ko.Scene(s2, q2, t2, m)
+    sc.set_texture(ko.TEX_HDRI, textures["hdri"]); sc.set_texture(ko.TEX_ALBEDO, textures["albedo"])
+    p = ko.default_params(width=w, height=h, mode=ko.MODE_PT, max_frames=0, max_bounces=8, use_bvh=1)
+    assert_bitexact(acc, ko.render_mean(sc, ko.default_camera(), p, 3), "refitted scene, path traced")
+
+
+def test_refit_rejects_what_it_cannot_do():
+    s, q, t, m = kl.synth_scene(blobs=4, tris_per_blob=160, analytic_spheres=4, seed=3)
+    with kl.Renderer(8, 8) as r:
+        with pytest.raises(kl.KlError):
+            r.refit_scene(s, q, t)                # nothing uploaded yet
+        r.upload_scene(s, q, t, m)
+        with pytest.raises(kl.KlError):
+            r.refit_scene(s, q, t[:-1])           # another primitive count
+        r.refit_scene(s, q, t)
+
+
+def test_refit_of_a_million_triangles():
+    from test_gpu_scene import random_rays
+    s, q, t, m = kl.synth_scene(blobs=1000, tris_per_blob=1000, seed=1)
+    s2, q2, t2 = _moved(s, q, t, 2)
+    o, d = random_rays(20000, 7)
+    with kl.Renderer(8, 8) as r:
+        r.update_params(accel=kl.ACCEL_BVH)
+        r.upload_scene(s, q, t, m)
+        build = r.bvh_stats().build_seconds
+        r.refit_scene(s2, q2, t2)
+        r.refit_scene(s2, q2, t2)
+        refit = r.bvh_stats().refit_seconds
+        ta, pa, ua = r.trace_rays(o, d)
+        r.upload_scene(s2, q2, t2, m)
+        tb, pb, ub = r.trace_rays(o, d)
+    assert np.array_equal(pa, pb)
+    assert_bitexact(ta, tb, "1M triangles refitted vs rebuilt: t"); assert_bitexact(ua, ub, "uv")
+    print("1M triangles: host SAH build %.4f s, refit %.4f s" % (build, refit))
+    assert refit < build
