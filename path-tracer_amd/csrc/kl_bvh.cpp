@@ -212,17 +212,136 @@ void collapse_node(const HostBVH &bvh, int32_t node2, uint32_t idx, std::vector<
     for (int k = 0; k < (int)ch.size(); k++)
         if (ch[k].ref >= 0) collapse_node(bvh, ch[k].ref, w[12 + k], out, depth + 1, max_depth);
 }
+
+// ---- collapse by dynamic programming over the binary tree --------------------------------------------------
+// Cost of a traversal = expected steps: one per 4-wide node entered, one per primitive of a leaf entered, each
+// weighted by the area of the box that guards it. For a binary node n and k = 1..4, f(n, k) = the cheapest way
+// to hang n's subtree under a 4-wide parent using at most k of the parent's slots: as ONE child (a 4-wide node
+// of its own: area + the best split of its two children over four slots; or, when its two children are leaves
+// of one type next to each other in the leaf order, one merged leaf: area x primitives), or with its two
+// children sharing the k slots. The greedy rule (open the largest child) is one of the shapes considered.
+inline uint32_t leaf_type(int32_t r) { return ((uint32_t)~r >> 29) & 3u; }
+inline uint32_t leaf_count(int32_t r) { return (((uint32_t)~r >> 26) & 7u) + 1u; }
+inline uint32_t leaf_start(int32_t r) { return (uint32_t)~r & 0x3FFFFFFu; }
+
+struct DpCollapse {
+    const HostBVH &bvh;
+    std::vector<float> f;            // 4 per binary node: f[4 n + k - 1]
+    std::vector<int32_t> merged;     // the merged leaf when that is n's best form as one child, else 0
+    std::vector<uint32_t> out;
+    uint32_t max_depth = 0, leaves = 0, max_leaf = 0;
+
+    explicit DpCollapse(const HostBVH &b) : bvh(b), f(b.nodes.size() / 16 * 4), merged(b.nodes.size() / 16, 0) {}
+    Child4 child_of(int32_t n2, int k) const {
+        const float *o = &bvh.nodes[(size_t)n2 * 16];
+        Child4 c;
+        for (int a = 0; a < 3; a++) { c.box.lo[a] = o[6 * k + a]; c.box.hi[a] = o[6 * k + 3 + a]; }
+        std::memcpy(&c.ref, o + 12 + k, 4);
+        return c;
+    }
+    float cost(const Child4 &c, int k) const { return c.ref < 0 ? c.box.area() * (float)leaf_count(c.ref) : f[(size_t)c.ref * 4 + k - 1]; }
+    // cheapest split of k slots between the two children; returns the cost, `left` = slots of child 0
+    float split(const Child4 &c0, const Child4 &c1, int k, int &left) const {
+        float best = std::numeric_limits<float>::infinity();
+        left = 1;
+        for (int i = 1; i < k; i++) {
+            const float c = cost(c0, i) + cost(c1, k - i);
+            if (c < best) { best = c; left = i; }
+        }
+        return best;
+    }
+    void solve(int32_t root) {       // children before parents, without recursion (a binary tree may be deep)
+        std::vector<std::pair<int32_t, bool>> stack = { { root, false } };
+        while (!stack.empty()) {
+            auto [n, ready] = stack.back(); stack.pop_back();
+            const Child4 c0 = child_of(n, 0), c1 = child_of(n, 1);
+            if (!ready) {
+                stack.push_back({ n, true });
+                if (c0.ref >= 0) stack.push_back({ c0.ref, false });
+                if (c1.ref >= 0) stack.push_back({ c1.ref, false });
+                continue;
+            }
+            Box nb = c0.box; nb.grow(c1.box);
+            const float area = nb.area();
+            int left;
+            float one = area + split(c0, c1, 4, left);
+            if (c0.ref < 0 && c1.ref < 0 && leaf_type(c0.ref) == leaf_type(c1.ref) && leaf_start(c1.ref) == leaf_start(c0.ref) + leaf_count(c0.ref)
+                && leaf_count(c0.ref) + leaf_count(c1.ref) <= LEAF_MAX) {
+                const float as_leaf = area * (float)(leaf_count(c0.ref) + leaf_count(c1.ref));
+                if (as_leaf <= one) { one = as_leaf; merged[n] = make_leaf(leaf_type(c0.ref), leaf_start(c0.ref), leaf_count(c0.ref) + leaf_count(c1.ref)); }
+            }
+            float *fn = &f[(size_t)n * 4];
+            fn[0] = one;
+            for (int k = 2; k <= 4; k++) fn[k - 1] = std::min(fn[k - 2], split(c0, c1, k, left));
+        }
+    }
+    // the children that `c` contributes to a 4-wide node when it may use up to k slots
+    void gather(const Child4 &c, int k, std::vector<Child4> &ch) const {
+        if (c.ref < 0) { ch.push_back(c); return; }
+        const Child4 c0 = child_of(c.ref, 0), c1 = child_of(c.ref, 1);
+        const float *fn = &f[(size_t)c.ref * 4];
+        while (k > 1) {
+            int left;
+            if (split(c0, c1, k, left) < fn[k - 2]) { gather(c0, left, ch); gather(c1, k - left, ch); return; }
+            k--;
+        }
+        Child4 one = c;
+        if (merged[c.ref]) one.ref = merged[c.ref];
+        ch.push_back(one);
+    }
+    void emit(int32_t node2, uint32_t idx, uint32_t depth) {
+        const Child4 c0 = child_of(node2, 0), c1 = child_of(node2, 1);
+        int left;
+        split(c0, c1, 4, left);
+        std::vector<Child4> ch;
+        gather(c0, left, ch); gather(c1, 4 - left, ch);
+        max_depth = std::max(max_depth, depth);
+        uint32_t w[16]; std::memset(w, 0, sizeof w);
+        float boxes[4][6];
+        for (size_t k = 0; k < ch.size(); k++)
+            for (int a = 0; a < 3; a++) { boxes[k][a] = ch[k].box.lo[a]; boxes[k][3 + a] = ch[k].box.hi[a]; }
+        node4_boxes(&boxes[0][0], (int)ch.size(), w);
+        uint32_t next = (uint32_t)(out.size() / 16);           // inner children: consecutive indices from here
+        uint32_t n_inner = 0;
+        for (const Child4 &c : ch) n_inner += c.ref >= 0 ? 1u : 0u;
+        out.resize(out.size() + (size_t)16 * n_inner, 0u);
+        for (size_t k = 0; k < ch.size(); k++) {
+            if (ch[k].ref >= 0) w[12 + k] = next++;
+            else { w[12 + k] = (uint32_t)ch[k].ref; leaves++; max_leaf = std::max(max_leaf, leaf_count(ch[k].ref)); }
+        }
+        for (size_t k = ch.size(); k < 4; k++) w[12 + k] = w[12];      // an empty slot repeats child 0 (see kl_types.hpp)
+        std::memcpy(&out[(size_t)idx * 16], w, sizeof w);
+        for (size_t k = 0; k < ch.size(); k++)
+            if (ch[k].ref >= 0) emit(ch[k].ref, w[12 + k], depth + 1);
+    }
+};
 }  // namespace
 
 void collapse_bvh4(HostBVH &bvh) {
     bvh.nodes4.clear(); bvh.depth4 = 0;
     bvh.root4 = bvh.root;                       // an empty tree or a lone leaf stays what it is
-    if (bvh.root >= 0 && bvh.root != NODE_DONE) {
+    if (bvh.root < 0 || bvh.root == NODE_DONE) return;
+    const char *how = std::getenv("KL_BVH_COLLAPSE");
+    if (how && std::strcmp(how, "greedy") == 0) {
         bvh.nodes4.reserve(bvh.nodes.size() / 2);
         bvh.nodes4.assign(16, 0u);                // the root is node 0
         collapse_node(bvh, bvh.root, 0u, bvh.nodes4, 1, bvh.depth4);
         bvh.root4 = 0;
+        return;
     }
+    DpCollapse dp(bvh);
+    dp.solve(bvh.root);
+    if (dp.merged[bvh.root]) {                  // the whole tree is one leaf
+        bvh.root4 = dp.merged[bvh.root];
+        bvh.stats.leaves = 1; bvh.stats.max_leaf_size = leaf_count(bvh.root4);
+        return;
+    }
+    dp.out.reserve(bvh.nodes.size() / 2);
+    dp.out.assign(16, 0u);
+    dp.emit(bvh.root, 0u, 1);
+    bvh.nodes4.swap(dp.out);
+    bvh.depth4 = dp.max_depth; bvh.root4 = 0;
+    bvh.stats.leaves = dp.leaves; bvh.stats.max_leaf_size = dp.max_leaf;
 }
 
 void identity_order(uint32_t ns, uint32_t nq, uint32_t nt, HostBVH &out) {
