@@ -35,7 +35,8 @@ struct TmpNode {
 };
 struct TmpLeaf { uint32_t type, start, count; };   // range in Builder::prims
 
-constexpr int NBINS = 16;
+constexpr int MAX_BINS = 64;
+static int NBINS = 16;
 // tuning knobs of the builder (environment overrides are for experiments): runs of at most leaf_target
 // primitives become a leaf without asking the SAH; trav_cost = cost of one binary node visit relative to one primitive test
 static uint32_t LEAF_TARGET = 2;
@@ -91,7 +92,7 @@ struct Builder {
                 float best_cost = std::numeric_limits<float>::infinity(); int best_axis = -1, best_bin = -1;
                 for (int ax = 0; ax < 3; ax++) {
                     if (!(ext[ax] > 0.0f)) continue;
-                    Box bb[NBINS]; uint32_t bn[NBINS];
+                    Box bb[MAX_BINS]; uint32_t bn[MAX_BINS];
                     for (int k = 0; k < NBINS; k++) { bb[k].reset(); bn[k] = 0; }
                     const float scale = (float)NBINS / ext[ax];
                     for (uint32_t i = b; i < e; i++) {
@@ -99,7 +100,7 @@ struct Builder {
                         k = k < 0 ? 0 : (k >= NBINS ? NBINS - 1 : k);
                         bb[k].grow(prims[i].box); bn[k]++;
                     }
-                    float right_area[NBINS]; uint32_t right_n[NBINS];
+                    float right_area[MAX_BINS]; uint32_t right_n[MAX_BINS];
                     Box acc; acc.reset(); uint32_t cnt = 0;
                     for (int k = NBINS - 1; k > 0; k--) { acc.grow(bb[k]); cnt += bn[k]; right_area[k] = acc.area(); right_n[k] = cnt; }
                     acc.reset(); cnt = 0;
@@ -361,6 +362,7 @@ void build_bvh(const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, c
     auto t0 = std::chrono::steady_clock::now();
     if (const char *e = std::getenv("KL_BVH_LEAF_TARGET")) LEAF_TARGET = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
     if (const char *e = std::getenv("KL_BVH_TRAV_COST")) TRAV_COST = (float)std::atof(e);
+    if (const char *e = std::getenv("KL_BVH_BINS")) NBINS = std::max(4, std::min(MAX_BINS, std::atoi(e)));
     uint32_t n = ns + nq + nt;
     identity_order(0, 0, 0, out);
     out.stats.spheres = ns; out.stats.quads = nq; out.stats.tris = nt;

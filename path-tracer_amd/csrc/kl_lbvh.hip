@@ -4,17 +4,20 @@
 //   keys       : 63-bit Morton-style code of the box centre, each bit halving the currently longest cell axis;
 //                candidates for the flat list
 //   sort       : hipCUB radix sort of (code, primitive); flat primitives carry the largest key and end up last
-//   orders     : per-type leaf orders (exclusive scans of the type flags over the sorted sequence)
-//   hierarchy  : binary radix tree over the sorted codes (Karras 2012), ties broken by position
-//   depth      : depth of every inner node (walk to the root; read-only data)
-//   refit      : boxes of the inner nodes, ONE LAUNCH PER DEPTH LEVEL from the deepest up: a node reads boxes
+//   cluster    : binary tree by locally-ordered clustering over the sorted sequence (k_ploc_*), whose left-to-right
+//                leaf order replaces the sorted order. With search radius 0 instead:
+//     hierarchy: binary radix tree over the sorted codes (Karras 2012), ties broken by position
+//     depth    : depth of every inner node (walk to the root; read-only data)
+//     refit    : boxes of the inner nodes, ONE LAUNCH PER DEPTH LEVEL from the deepest up: a node reads boxes
 //                that an earlier launch wrote, so no hand-off between workgroups happens inside a launch
+//   orders     : per-type leaf orders (exclusive scans of the type flags over the leaf sequence)
 //   collapse   : 4-wide nodes with 8-bit child boxes, one launch per 4-wide level from the root down; a node
 //                opens its inner child with the largest box until it has four children (as the host collapse)
 #include "kl_lbvh.hpp"
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -464,6 +467,92 @@ __global__ __launch_bounds__(256) void k_refit_nodes(uint32_t level, uint32_t n_
     nhi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
 }
 
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) -------------------------------------
+// Bottom-up agglomeration over the Morton-ordered primitives: every cluster looks `radius` places to either side
+// for the neighbour whose union with it has the smallest area; two clusters that choose each other merge into a
+// new binary node; the survivors are compacted, still in Morton order, and the search repeats until one cluster
+// is left. Candidate pairs are ranked by (area, distance in the sequence, a hash of the lower position): a total
+// order that both ends of a pair evaluate alike, so the best pair of any neighbourhood is always mutual and a run
+// of identical boxes still pairs off a third of its members per pass.
+__device__ __forceinline__ uint32_t ploc_hash(uint32_t x) { x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16; return x; }
+__global__ __launch_bounds__(256) void k_ploc_init(uint32_t n, const uint32_t *vals, const float4 *blo, const float4 *bhi, int *cid, float4 *clo, float4 *chi) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = vals[i];
+    cid[i] = ~(int)i; clo[i] = blo[g]; chi[i] = bhi[g];
+}
+__global__ __launch_bounds__(256) void k_ploc_nn(uint32_t n, int radius, const float4 *clo, const float4 *chi, uint32_t *nn) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= (int)n) return;
+    const float4 a = clo[i], b = chi[i];
+    float best = __builtin_huge_valf(); int bj = -1; uint32_t bdist = 0, bh = 0;
+    const int j0 = max(0, i - radius), j1 = min((int)n - 1, i + radius);
+    for (int j = j0; j <= j1; j++) {
+        if (j == i) continue;
+        const float4 c = clo[j], d = chi[j];
+        const float dx = fmaxf(b.x, d.x) - fminf(a.x, c.x), dy = fmaxf(b.y, d.y) - fminf(a.y, c.y), dz = fmaxf(b.z, d.z) - fminf(a.z, c.z);
+        const float area = dx * dy + dy * dz + dz * dx;
+        const uint32_t dist = (uint32_t)abs(j - i), h = ploc_hash((uint32_t)min(i, j));
+        if (area < best || (area == best && (dist < bdist || (dist == bdist && h < bh)))) { best = area; bj = j; bdist = dist; bh = h; }
+    }
+    nn[i] = (uint32_t)bj;
+}
+// mutual pairs become a node at the lower position; cnt = leaves below a node, parents for the walk that orders the leaves
+__global__ __launch_bounds__(256) void k_ploc_merge(uint32_t n, const uint32_t *nn, int *cid, float4 *clo, float4 *chi, uint32_t *n_nodes,
+                                                    int *left, int *right, float4 *ilo, float4 *ihi, uint32_t *cnt, int *pint, int *pleaf, uint32_t *keep) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = nn[i];
+    if (j >= n || nn[j] != i) { keep[i] = 1u; return; }
+    if (j < i) { keep[i] = 0u; return; }
+    const int l = cid[i], r = cid[j];
+    const float4 a = clo[i], b = chi[i], c = clo[j], d = chi[j];
+    const float4 lo = make_float4(fminf(a.x, c.x), fminf(a.y, c.y), fminf(a.z, c.z), 0.0f), hi = make_float4(fmaxf(b.x, d.x), fmaxf(b.y, d.y), fmaxf(b.z, d.z), 0.0f);
+    const int node = (int)atomicAdd(n_nodes, 1u);
+    left[node] = l; right[node] = r; ilo[node] = lo; ihi[node] = hi;
+    cnt[node] = (l < 0 ? 1u : cnt[l]) + (r < 0 ? 1u : cnt[r]);
+    if (l < 0) pleaf[~l] = node; else pint[l] = node;
+    if (r < 0) pleaf[~r] = node; else pint[r] = node;
+    pint[node] = -1;
+    cid[i] = node; clo[i] = lo; chi[i] = hi;
+    keep[i] = 1u;
+}
+__global__ __launch_bounds__(256) void k_ploc_compact(uint32_t n, const uint32_t *keep, const uint32_t *pos, const int *cid, const float4 *clo, const float4 *chi,
+                                                      int *cid2, float4 *clo2, float4 *chi2, uint32_t *n_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (keep[i]) { const uint32_t p = pos[i]; cid2[p] = cid[i]; clo2[p] = clo[i]; chi2[p] = chi[i]; }
+    if (i == n - 1) *n_out = pos[i] + keep[i];
+}
+// place of every leaf in a left-to-right walk of the finished tree = leaves under the left siblings along its way up
+__global__ __launch_bounds__(256) void k_ploc_rank(uint32_t n, const int *pleaf, const int *pint, const int *left, const int *right, const uint32_t *cnt,
+                                                   uint32_t *rank, uint32_t *maxdepth) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t d = 0;
+    if (i < n) {
+        uint32_t r = 0;
+        int child = ~(int)i, p = pleaf[i];
+        while (p >= 0 && d < WALK_CAP) {
+            if (right[p] == child) { const int l = left[p]; r += l < 0 ? 1u : cnt[l]; }
+            child = p; p = pint[p]; d++;
+        }
+        rank[i] = r;
+    }
+    for (int off = 32; off > 0; off >>= 1) d = max(d, (uint32_t)__shfl_xor((int)d, off));
+    if ((threadIdx.x & 63u) == 0u) atomicMax(maxdepth, d);
+}
+__global__ __launch_bounds__(256) void k_ploc_reorder(uint32_t n, const uint32_t *rank, const uint32_t *vals, uint32_t *vals2) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) vals2[rank[i]] = vals[i];
+}
+__global__ __launch_bounds__(256) void k_ploc_remap(uint32_t n_int, const uint32_t *rank, int *left, int *right) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_int) return;
+    const int l = left[i], r = right[i];
+    if (l < 0) left[i] = ~(int)rank[~l];
+    if (r < 0) right[i] = ~(int)rank[~r];
+}
+
 struct Buf {
     void *p = nullptr;
     ~Buf() { if (p) (void)hipFree(p); }
@@ -521,6 +610,8 @@ LbvhResult build_bvh_gpu(hipStream_t stream, const kl_sphere *s, uint32_t ns, co
         hipLaunchKernelGGL(k_lbvh_mark_flat, dim3(blocks_for(nflat)), dim3(256), 0, stream, d_flat.as<uint32_t>(), nflat, d_keys[0].as<unsigned long long>());
     }
     const uint32_t n_tree = n - nflat;
+    int ploc_radius = 12;                // 0: the radix tree over the codes instead of clustering
+    if (const char *e = std::getenv("KL_PLOC_RADIUS")) ploc_radius = std::max(0, std::min(64, std::atoi(e)));
     // Morton order
     size_t tmp_bytes = 0;
     LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys[0].as<unsigned long long>(), d_keys[1].as<unsigned long long>(),
@@ -532,7 +623,59 @@ LbvhResult build_bvh_gpu(hipStream_t stream, const kl_sphere *s, uint32_t ns, co
                                           d_vals[0].as<uint32_t>(), d_vals[1].as<uint32_t>(), (int)n, 0, 64, stream));
     const unsigned long long *keys = d_keys[1].as<unsigned long long>();
     const uint32_t *vals = d_vals[1].as<uint32_t>();
-    // per-type leaf orders; d_vals[0] and d_keys[0] are free again and serve as scratch
+    // tree over the first n_tree positions
+    Buf d_left, d_right, d_pint, d_pleaf, d_depth, d_maxdepth, d_ilo, d_ihi, d_src, d_alloc, d_nodes4;
+    uint32_t count4 = 0, depth4 = 0, maxdepth = 0;
+    int32_t root4 = NODE_DONE, root2 = 0;
+    const uint32_t n_int = n_tree >= 2 ? n_tree - 1 : 0;
+    if (n_int) {
+        LB(d_left.alloc((size_t)n_int * 4)); LB(d_right.alloc((size_t)n_int * 4)); LB(d_pint.alloc((size_t)n_int * 4)); LB(d_pleaf.alloc((size_t)n_tree * 4));
+        LB(d_maxdepth.alloc(4)); LB(d_ilo.alloc((size_t)n_int * 16)); LB(d_ihi.alloc((size_t)n_int * 16));
+        LB(d_src.alloc((size_t)n_int * 4)); LB(d_alloc.alloc(4)); LB(d_nodes4.alloc((size_t)n_int * 64));
+        LB(hipMemsetAsync(d_maxdepth.p, 0, 4, stream));
+    }
+    if (n_int && ploc_radius > 0) {
+        // agglomerative build; it also decides the leaf order (left to right in its tree), so it comes before the orders
+        Buf d_cid[2], d_clo[2], d_chi[2], d_nn, d_keep, d_pos, d_cnt, d_count, d_rank;
+        for (int k = 0; k < 2; k++) { LB(d_cid[k].alloc((size_t)n_tree * 4)); LB(d_clo[k].alloc((size_t)n_tree * 16)); LB(d_chi[k].alloc((size_t)n_tree * 16)); }
+        LB(d_nn.alloc((size_t)n_tree * 4)); LB(d_keep.alloc((size_t)n_tree * 4)); LB(d_pos.alloc((size_t)n_tree * 4)); LB(d_cnt.alloc((size_t)n_int * 4));
+        LB(d_count.alloc(4)); LB(d_rank.alloc((size_t)n_tree * 4));
+        LB(hipMemsetAsync(d_alloc.p, 0, 4, stream));              // node counter during the clustering
+        hipLaunchKernelGGL(k_ploc_init, dim3(blocks_for(n_tree)), dim3(256), 0, stream, n_tree, vals, d_blo.as<float4>(), d_bhi.as<float4>(),
+                           d_cid[0].as<int>(), d_clo[0].as<float4>(), d_chi[0].as<float4>());
+        uint32_t live = n_tree, passes = 0;
+        int cur = 0;
+        while (live > 1) {
+            if (++passes > 8192) { err = "clustering does not converge"; return LBVH_TOO_DEEP; }
+            hipLaunchKernelGGL(k_ploc_nn, dim3(blocks_for(live)), dim3(256), 0, stream, live, ploc_radius, d_clo[cur].as<float4>(), d_chi[cur].as<float4>(), d_nn.as<uint32_t>());
+            hipLaunchKernelGGL(k_ploc_merge, dim3(blocks_for(live)), dim3(256), 0, stream, live, d_nn.as<uint32_t>(), d_cid[cur].as<int>(), d_clo[cur].as<float4>(),
+                               d_chi[cur].as<float4>(), d_alloc.as<uint32_t>(), d_left.as<int>(), d_right.as<int>(), d_ilo.as<float4>(), d_ihi.as<float4>(),
+                               d_cnt.as<uint32_t>(), d_pint.as<int>(), d_pleaf.as<int>(), d_keep.as<uint32_t>());
+            LB(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, scan_bytes, d_keep.as<uint32_t>(), d_pos.as<uint32_t>(), (int)live, stream));
+            hipLaunchKernelGGL(k_ploc_compact, dim3(blocks_for(live)), dim3(256), 0, stream, live, d_keep.as<uint32_t>(), d_pos.as<uint32_t>(), d_cid[cur].as<int>(),
+                               d_clo[cur].as<float4>(), d_chi[cur].as<float4>(), d_cid[cur ^ 1].as<int>(), d_clo[cur ^ 1].as<float4>(), d_chi[cur ^ 1].as<float4>(),
+                               d_count.as<uint32_t>());
+            uint32_t next = 0;
+            LB(hipMemcpyAsync(&next, d_count.p, 4, hipMemcpyDeviceToHost, stream));
+            LB(hipStreamSynchronize(stream));
+            if (next == 0 || next >= live) { err = "clustering pass merged nothing"; return LBVH_HIP_ERROR; }
+            live = next; cur ^= 1;
+        }
+        LB(hipMemcpyAsync(&root2, d_cid[cur].p, 4, hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL(k_ploc_rank, dim3(blocks_for(n_tree)), dim3(256), 0, stream, n_tree, d_pleaf.as<int>(), d_pint.as<int>(), d_left.as<int>(), d_right.as<int>(),
+                           d_cnt.as<uint32_t>(), d_rank.as<uint32_t>(), d_maxdepth.as<uint32_t>());
+        LB(hipMemcpyAsync(&maxdepth, d_maxdepth.p, 4, hipMemcpyDeviceToHost, stream));
+        LB(hipStreamSynchronize(stream));
+        if (maxdepth >= WALK_CAP) { err = "clustered tree deeper than the builder's walk bound"; return LBVH_TOO_DEEP; }
+        if (root2 < 0 || (uint32_t)root2 >= n_int) { err = "clustering left no root"; return LBVH_HIP_ERROR; }
+        // the sorted sequence rearranged into the tree's leaf order (the flat tail stays where it is)
+        LB(hipMemcpyAsync(d_vals[0].p, d_vals[1].p, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(k_ploc_reorder, dim3(blocks_for(n_tree)), dim3(256), 0, stream, n_tree, d_rank.as<uint32_t>(), d_vals[1].as<uint32_t>(), d_vals[0].as<uint32_t>());
+        hipLaunchKernelGGL(k_ploc_remap, dim3(blocks_for(n_int)), dim3(256), 0, stream, n_int, d_rank.as<uint32_t>(), d_left.as<int>(), d_right.as<int>());
+        LB(hipStreamSynchronize(stream));            // the clustering's buffers go out of scope here
+        vals = d_vals[0].as<uint32_t>();
+    }
+    // per-type leaf orders; d_keys[0] is free again and serves as scratch
     Buf d_f[3], d_r[3], d_ord[3], d_leafref;
     for (int k = 0; k < 3; k++) { LB(d_f[k].alloc((size_t)n * 4)); LB(d_r[k].alloc((size_t)n * 4)); }
     LB(d_ord[0].alloc((size_t)ns * 4)); LB(d_ord[1].alloc((size_t)nq * 4)); LB(d_ord[2].alloc((size_t)nt * 4));
@@ -542,31 +685,26 @@ LbvhResult build_bvh_gpu(hipStream_t stream, const kl_sphere *s, uint32_t ns, co
         LB(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, scan_bytes, d_f[k].as<uint32_t>(), d_r[k].as<uint32_t>(), (int)n, stream));
     hipLaunchKernelGGL(k_lbvh_orders, dim3(blocks_for(n)), dim3(256), 0, stream, vals, n, ns, nq, d_r[0].as<uint32_t>(), d_r[1].as<uint32_t>(), d_r[2].as<uint32_t>(),
                        d_ord[0].as<uint32_t>(), d_ord[1].as<uint32_t>(), d_ord[2].as<uint32_t>(), d_leafref.as<int>());
-    // tree over the first n_tree positions
-    Buf d_left, d_right, d_pint, d_pleaf, d_depth, d_maxdepth, d_ilo, d_ihi, d_src, d_alloc, d_nodes4;
-    uint32_t count4 = 0, depth4 = 0, maxdepth = 0;
-    int32_t root4 = NODE_DONE;
     if (n_tree == 1) {
         LB(hipMemcpyAsync(&root4, d_leafref.p, 4, hipMemcpyDeviceToHost, stream));
         LB(hipStreamSynchronize(stream));
     } else if (n_tree >= 2) {
-        const uint32_t n_int = n_tree - 1;
-        LB(d_left.alloc((size_t)n_int * 4)); LB(d_right.alloc((size_t)n_int * 4)); LB(d_pint.alloc((size_t)n_int * 4)); LB(d_pleaf.alloc((size_t)n_tree * 4));
-        LB(d_depth.alloc((size_t)n_int * 4)); LB(d_maxdepth.alloc(4)); LB(d_ilo.alloc((size_t)n_int * 16)); LB(d_ihi.alloc((size_t)n_int * 16));
-        LB(d_src.alloc((size_t)n_int * 4)); LB(d_alloc.alloc(4)); LB(d_nodes4.alloc((size_t)n_int * 64));
-        LB(hipMemsetAsync(d_maxdepth.p, 0, 4, stream));
-        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(blocks_for(n_int)), dim3(256), 0, stream, keys, (int)n_tree, d_left.as<int>(), d_right.as<int>(),
-                           d_pint.as<int>(), d_pleaf.as<int>());
-        hipLaunchKernelGGL(k_lbvh_depth, dim3(blocks_for(n_int)), dim3(256), 0, stream, d_pint.as<int>(), n_int, d_depth.as<uint32_t>(), d_maxdepth.as<uint32_t>());
-        LB(hipMemcpyAsync(&maxdepth, d_maxdepth.p, 4, hipMemcpyDeviceToHost, stream));
-        LB(hipStreamSynchronize(stream));
-        if (maxdepth >= WALK_CAP) { err = "radix tree deeper than the builder's walk bound"; return LBVH_TOO_DEEP; }
-        for (uint32_t level = maxdepth + 1; level-- > 0;)
-            hipLaunchKernelGGL(k_lbvh_refit, dim3(blocks_for(n_int)), dim3(256), 0, stream, level, d_depth.as<uint32_t>(), n_int, d_left.as<int>(), d_right.as<int>(),
-                               vals, d_blo.as<float4>(), d_bhi.as<float4>(), d_ilo.as<float4>(), d_ihi.as<float4>());
-        // collapse, level by level from the root (4-wide node 0 = binary node 0)
-        const int zero = 0; const uint32_t one = 1;
-        LB(hipMemcpyAsync(d_src.p, &zero, 4, hipMemcpyHostToDevice, stream));
+        if (ploc_radius <= 0) {
+            // binary radix tree over the sorted codes, boxes by one refit launch per depth level
+            LB(d_depth.alloc((size_t)n_int * 4));
+            hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(blocks_for(n_int)), dim3(256), 0, stream, keys, (int)n_tree, d_left.as<int>(), d_right.as<int>(),
+                               d_pint.as<int>(), d_pleaf.as<int>());
+            hipLaunchKernelGGL(k_lbvh_depth, dim3(blocks_for(n_int)), dim3(256), 0, stream, d_pint.as<int>(), n_int, d_depth.as<uint32_t>(), d_maxdepth.as<uint32_t>());
+            LB(hipMemcpyAsync(&maxdepth, d_maxdepth.p, 4, hipMemcpyDeviceToHost, stream));
+            LB(hipStreamSynchronize(stream));
+            if (maxdepth >= WALK_CAP) { err = "radix tree deeper than the builder's walk bound"; return LBVH_TOO_DEEP; }
+            for (uint32_t level = maxdepth + 1; level-- > 0;)
+                hipLaunchKernelGGL(k_lbvh_refit, dim3(blocks_for(n_int)), dim3(256), 0, stream, level, d_depth.as<uint32_t>(), n_int, d_left.as<int>(), d_right.as<int>(),
+                                   vals, d_blo.as<float4>(), d_bhi.as<float4>(), d_ilo.as<float4>(), d_ihi.as<float4>());
+        }
+        // collapse, level by level from the root (4-wide node 0 = the binary root)
+        const uint32_t one = 1;
+        LB(hipMemcpyAsync(d_src.p, &root2, 4, hipMemcpyHostToDevice, stream));
         LB(hipMemcpyAsync(d_alloc.p, &one, 4, hipMemcpyHostToDevice, stream));
         uint32_t begin = 0, end = 1;
         while (begin < end) {

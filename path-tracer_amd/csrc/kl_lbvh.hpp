@@ -1,4 +1,4 @@
-// GPU-side BVH builder and refit (no reference counterpart): Morton-ordered LBVH, refit, collapse into the 4-wide
+// GPU-side BVH builder and refit (no reference counterpart): Morton order, clustering (or radix tree), collapse into the 4-wide
 // quantised nodes of kl_types.hpp. Same output contract as the host builder (kl_bvh.hpp): it fills the
 // 4-wide part of HostBVH (nodes4, root4, depth4), the per-type leaf orders and the flat-primitive ranges, so
 // everything downstream of the builder (record packing, traversal) is the same code for both.

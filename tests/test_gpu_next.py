@@ -115,10 +115,14 @@ def _trace_both(r, o, d):
     return tb, tf
 
 
-def test_gpu_built_tree_finds_the_same_hits():
-    """the Morton-ordered tree built on the GPU against the flat loop and against the host SAH tree: same primitive,
-    same t and uv bit for bit (the closest hit does not depend on the tree), degenerate inputs included"""
+@pytest.mark.parametrize("radius", [None, "0", "3"])
+def test_gpu_built_tree_finds_the_same_hits(radius, monkeypatch):
+    """the tree built on the GPU (clustering with the default search radius, the radix tree over the codes instead
+    = radius 0, a small radius) against the flat loop and against the host SAH tree: same primitive, same t and uv
+    bit for bit (the closest hit does not depend on the tree), degenerate inputs included"""
     from test_gpu_scene import random_rays
+    if radius is not None:
+        monkeypatch.setenv("KL_PLOC_RADIUS", radius)
     s, q, t, m = kl.synth_scene(blobs=24, tris_per_blob=160, analytic_spheres=40, seed=3)
     o, d = random_rays(3000, 13)
     o[:50] = t["v0"][:50]
