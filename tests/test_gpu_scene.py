@@ -231,3 +231,53 @@ def test_shared_camera_ray_hits_do_not_change_the_image(mode, small_scene, textu
     c, _ = run(0, shard=(1, 3, 5))
     rows = [y for y in range(h) if (y // 5) % 3 == 1]
     assert_bitexact(c, a[rows], "shared camera-ray hits on a shard")
+
+
+def _soup(rng, ns, nq, nt, nm=5):
+    """random primitives with no structure at all: tiny and huge, slivers, overlapping, one degenerate"""
+    s = np.zeros(ns, dtype=kl.sphere_dtype); q = np.zeros(nq, dtype=kl.quad_dtype); t = np.zeros(nt, dtype=kl.tri_dtype)
+    m = np.zeros(nm, dtype=kl.material_dtype)
+    m["type"] = rng.integers(0, 4, nm); m["color"] = rng.random((nm, 3)); m["roughness"] = rng.random(nm); m["ior"] = 1.3
+    span = np.array([4.0, 3.0, 8.0], dtype=np.float32)
+    s["center"] = (rng.random((ns, 3)) - 0.5) * span; s["radius"] = np.exp(rng.uniform(np.log(0.01), np.log(0.8), ns))
+    s["material"] = rng.integers(0, nm, ns)
+    c = (rng.random((nq, 3)) - 0.5) * span                            # parallelograms: planar by construction
+    a = rng.normal(size=(nq, 3)) * np.exp(rng.uniform(np.log(0.02), np.log(2.0), (nq, 1)))
+    b = rng.normal(size=(nq, 3)) * np.exp(rng.uniform(np.log(0.02), np.log(2.0), (nq, 1)))
+    q["v0"] = c; q["v1"] = c + a; q["v2"] = c + a + b; q["v3"] = c + b; q["material"] = rng.integers(0, nm, nq)
+    c = (rng.random((nt, 3)) - 0.5) * span
+    size = np.exp(rng.uniform(np.log(0.005), np.log(3.0), (nt, 1)))
+    t["v0"] = c; t["v1"] = c + rng.normal(size=(nt, 3)) * size; t["v2"] = c + rng.normal(size=(nt, 3)) * size
+    t["uv0"] = rng.random((nt, 2)); t["uv1"] = rng.random((nt, 2)); t["uv2"] = rng.random((nt, 2))
+    t["material"] = rng.integers(0, nm, nt)
+    if nt > 3:
+        t[3]["v2"] = t[3]["v1"]                                      # zero area
+    return s, q, t, m
+
+
+@pytest.mark.parametrize("counts", [(1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 2), (3, 2, 4), (0, 0, 33), (5, 5, 40), (40, 25, 700), (300, 60, 5000)])
+def test_random_soups_tree_equals_flat_loop_equals_oracle(counts):
+    """scenes without any structure, from one primitive up: host tree, GPU-built tree and a tree refitted from another
+    soup of the same counts all find the flat loop's hits, and the oracle's, bit for bit"""
+    rng = np.random.default_rng(1000 + sum(counts))
+    s, q, t, m = _soup(rng, *counts)
+    s0, q0, t0, _ = _soup(rng, *counts)
+    o, d = random_rays(1500, 23, box=((-3.0, -2.5, -5.0), (3.0, 2.5, 5.0)))
+    got = {}
+    with kl.Renderer(8, 8) as r:
+        for name, builder in (("host", kl.BUILD_HOST_SAH), ("gpu", kl.BUILD_GPU_LBVH)):
+            r.update_params(bvh_builder=builder, accel=kl.ACCEL_BVH)
+            r.upload_scene(s, q, t, m)
+            got[name] = r.trace_rays(o, d)
+            r.upload_scene(s0, q0, t0, m)                            # a tree built for other geometry ...
+            r.refit_scene(s, q, t)                                   # ... bent onto this one
+            got[name + " refit"] = r.trace_rays(o, d)
+        r.update_params(accel=kl.ACCEL_BRUTE)
+        tf, pf, uf = r.trace_rays(o, d)
+    for name, (tb, pb, ub) in got.items():
+        assert np.array_equal(pb, pf), name
+        assert_bitexact(tb, tf, name + ": t"); assert_bitexact(ub, uf, name + ": uv")
+    sc = ko.Scene(s, q, t, m)
+    to, po, uo = oracle_trace(sc, o[:300], d[:300], 1)
+    assert np.array_equal(np.where(po < 0, kl.MISS, po).astype(np.uint32), pf[:300])
+    assert_bitexact(to, tf[:300], "t vs oracle"); assert_bitexact(uo, uf[:300], "uv vs oracle")
