@@ -690,7 +690,7 @@ __device__ __forceinline__ ShadeIn shade_load(const RayQueue &q, uint32_t i) {
 #define KL_SHADE_MIN_WAVES 1
 #endif
 template <int MODE>
-__global__ __launch_bounds__(256, KL_SHADE_MIN_WAVES) void k_shade(SceneDev sc, FrameDev f, RayQueue qin,
+__global__ __launch_bounds__(256, KL_SHADE_MIN_WAVES) void k_shade(SceneDev sc_by_value, FrameDev f, RayQueue qin,
                                                const uint32_t *counts_in, RayQueue qout, uint32_t *counts_out,
                                                float4 *raw, uint32_t bounce, uint32_t fused, uint32_t flat) {
     // block b works on segment b % nseg; survivors stay in their segment
@@ -705,6 +705,15 @@ __global__ __launch_bounds__(256, KL_SHADE_MIN_WAVES) void k_shade(SceneDev sc, 
     nxt.od = make_float4(0, 0, 0, 0); nxt.dt = make_float4(0, 0, 0, 0); nxt.tp = make_float4(0, 0, 0, 0);
     if (wave * 64u + lane < count) nxt = shade_load(qin, seg_base + wave * 64u + lane);
     for (uint32_t base = wave * 64u; base < count; base += nwaves * 64u) {
+        // The scene description (32 words, the kernel's first argument) is read where it is used, by scalar loads from
+        // the kernel-argument segment, instead of being held in scalar registers across the loop: together with the
+        // frame description and the flat-quad table it does not fit there, and the compiler then parks scalars in
+        // vector-register lanes and fetches them back one v_readlane at a time (58 per iteration, and 6 vector
+        // registers: 84 -> 78, a sixth wave per SIMD). The empty asm makes the pointer opaque in every iteration,
+        // so the loads cannot be hoisted back out of the loop.
+        auto kernarg = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kernarg));
+        const SceneDev &sc = *(const SceneDev *)(const __attribute__((address_space(4))) SceneDev *)kernarg;
         const uint32_t i = seg_base + base + lane;
         const bool valid = base + lane < count;
         const ShadeIn in = nxt;
