@@ -384,7 +384,10 @@ __device__ __forceinline__ void coop_fetch_one(const float4 *base, uint32_t my_o
 #ifndef KL_ISECT_MIN_WAVES
 #define KL_ISECT_MIN_WAVES 6       // waves per SIMD the register allocation must allow (<= 80 VGPRs)
 #endif
-template <bool STATS>
+// TYPES: which primitive types the tree holds (bit PRIM_*). The leaf branch of a kernel built for one type is that
+// type's test alone; the test code of types a scene does not have costs registers even if it never runs (all three:
+// 80 VGPRs and two spilled; triangles only: 54), and with them the scheduling freedom of the whole loop.
+template <bool STATS, uint32_t TYPES>
 __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_intersect_bvh(SceneDev sc, FrameDev f, RayQueue q, uint32_t tally_flat,
                                                                    const uint32_t *counts, uint32_t *heads, Counters *cn, int *overflow) {
     __shared__ int stack[ISECT_WAVES][ISECT_LDS_STACK][64];
@@ -548,9 +551,10 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                         node = ref[0];
                     } else pop = true;
                 } else {
-                    if (type == PRIM_TRI) { test_tri(n0, n1, n2, start, o, d, h, &sc); if (STATS) s_tri++; }
-                    else if (type == PRIM_SPHERE) { test_sphere(n0, n1, start, o, d, f.eps, h, &sc); if (STATS) s_sph++; }
-                    else { test_quad(n0, n1, n2, n3, start, o, d, h, &sc); if (STATS) s_quad++; }
+                    constexpr uint32_t T = 1u << PRIM_TRI, S = 1u << PRIM_SPHERE, Q = 1u << PRIM_QUAD;
+                    if (TYPES == T || ((TYPES & T) && type == PRIM_TRI)) { test_tri(n0, n1, n2, start, o, d, h, &sc); if (STATS) s_tri++; }
+                    else if (TYPES == S || ((TYPES & S) && type == PRIM_SPHERE)) { test_sphere(n0, n1, start, o, d, f.eps, h, &sc); if (STATS) s_sph++; }
+                    else if (TYPES & Q) { test_quad(n0, n1, n2, n3, start, o, d, h, &sc); if (STATS) s_quad++; }
                     if ((lv >> 26) & 7u) node = ~(int)(lv + 1u - (1u << 26));   // next primitive of this leaf
                     else pop = true;
                 }
@@ -957,8 +961,21 @@ void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, co
     }
     const uint32_t tally_flat = (scene_has_flat(sc) && flat_by_producer) ? 1u : 0u;
     uint32_t blocks = seg_grid(f, max_rays, lc.cus * lc.isect_blocks_per_cu, ISECT_CHUNK * ISECT_WAVES);
-    if (stats) hipLaunchKernelGGL(k_intersect_bvh<true>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, tally_flat, counts, heads, cn, overflow);
-    else hipLaunchKernelGGL(k_intersect_bvh<false>, dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, tally_flat, counts, heads, cn, overflow);
+    // the kernel built for the primitive types this tree holds (the instrumented variant: one kernel for all)
+    uint32_t types = 0u;
+    for (uint32_t t = 0; t < 3u; t++) types |= sc.count[t] > sc.flat_count[t] ? 1u << t : 0u;
+#define KL_ISECT_LAUNCH(ST, TY) hipLaunchKernelGGL((k_intersect_bvh<ST, TY>), dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, tally_flat, counts, heads, cn, overflow)
+    if (stats) { KL_ISECT_LAUNCH(true, 7u); return; }
+    switch (types) {
+        case 1u: KL_ISECT_LAUNCH(false, 1u); break;
+        case 2u: KL_ISECT_LAUNCH(false, 2u); break;
+        case 3u: KL_ISECT_LAUNCH(false, 3u); break;
+        case 4u: KL_ISECT_LAUNCH(false, 4u); break;
+        case 5u: KL_ISECT_LAUNCH(false, 5u); break;
+        case 6u: KL_ISECT_LAUNCH(false, 6u); break;
+        default: KL_ISECT_LAUNCH(false, 7u); break;
+    }
+#undef KL_ISECT_LAUNCH
 }
 void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin,
                   const uint32_t *count_in, RayQueue qout, uint32_t *count_out, float4 *raw, uint32_t bounce, bool fused,
