@@ -435,6 +435,8 @@ kl_status kl_create(kl_ctx **out, int32_t device, uint32_t width, uint32_t heigh
 #define KL_ISECT_BLOCKS_PER_CU 6     // 4 waves x (2.5 KiB stack + 4.1 KiB fetch staging) -> six workgroups share a CU's 160 KiB LDS
 #endif
     c->lc.isect_blocks_per_cu = KL_ISECT_BLOCKS_PER_CU;
+    c->lc.shade_blocks_per_cu = 8;
+    if (const char *e = std::getenv("KL_SHADE_BLOCKS_PER_CU")) c->lc.shade_blocks_per_cu = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("KL_FLAT_SEPARATE")) c->flat_separate = e[0] == '1';
     c->width = width; c->height = height;
     kl_default_camera(&c->cam);

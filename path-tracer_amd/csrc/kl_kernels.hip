@@ -980,7 +980,7 @@ void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, co
 void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin,
                   const uint32_t *count_in, RayQueue qout, uint32_t *count_out, float4 *raw, uint32_t bounce, bool fused,
                   uint32_t max_rays, bool flat) {
-    dim3 g(seg_grid(f, max_rays, lc.cus * 8u, 256u)), b(256);
+    dim3 g(seg_grid(f, max_rays, lc.cus * lc.shade_blocks_per_cu, 256u)), b(256);
     const uint32_t fu = fused ? 1u : 0u, fl = (fused && flat) ? 1u : 0u;
     if (f.mode == KL_MODE_PT) hipLaunchKernelGGL(k_shade<KL_MODE_PT>, g, b, 0, s, sc, f, qin, count_in, qout, count_out, raw, bounce, fu, fl);
     else if (f.mode == KL_MODE_AO) hipLaunchKernelGGL(k_shade<KL_MODE_AO>, g, b, 0, s, sc, f, qin, count_in, qout, count_out, raw, bounce, fu, fl);

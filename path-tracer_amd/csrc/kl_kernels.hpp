@@ -9,6 +9,7 @@ namespace kl {
 struct LaunchCfg {
     uint32_t cus;                    // compute units of the device
     uint32_t isect_blocks_per_cu;    // resident traversal workgroups per CU (bounded by LDS and VGPRs)
+    uint32_t shade_blocks_per_cu;    // upper bound of the shade grid, in 256-thread workgroups per CU
 };
 
 // Every ray leaves generate with its closest hit so far in its queue entry: copied from the one-frame queue `seed`
