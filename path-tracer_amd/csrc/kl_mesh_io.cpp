@@ -3,9 +3,12 @@
 // empty Ngon / Mesh) and no loader; this follows their shape: polygons become triangle fans, texture
 // coordinates ride along per corner, everything else in the files (normals, groups, material libraries,
 // colours) is skipped.
+#include <cctype>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <new>
 #include <sstream>
@@ -18,6 +21,8 @@ namespace {
 
 struct V3 { float x, y, z; };
 struct V2 { float u, v; };
+constexpr size_t kMaxElements = (size_t)1 << 27;    // vertices or faces of one file
+constexpr size_t kMaxTriangles = (size_t)1 << 25;   // the scene limit of kl_upload_scene
 
 void put(kl_tri &t, const V3 &a, const V3 &b, const V3 &c, const V2 &ta, const V2 &tb, const V2 &tc, uint32_t material) {
     t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z;
@@ -77,6 +82,7 @@ bool load_obj(const char *path, uint32_t material, uint32_t n_materials, std::ve
             }
             if (vi.size() < 3) { err = std::string(path) + ":" + std::to_string(lineno) + ": face with fewer than 3 corners"; return false; }
             const V2 zero{0, 0};
+            if (out.size() + vi.size() > kMaxTriangles) { err = "more than 2^25 triangles"; return false; }
             for (size_t k = 1; k + 1 < vi.size(); k++) {       // triangle fan
                 kl_tri t;
                 put(t, v[vi[0]], v[vi[k]], v[vi[k + 1]], ti[0] >= 0 ? vt[ti[0]] : zero, ti[k] >= 0 ? vt[ti[k]] : zero,
@@ -136,7 +142,9 @@ bool load_ply(const char *path, uint32_t material, std::vector<kl_tri> &out, std
             else if (f == "binary_little_endian") ascii = false;
             else { err = "PLY format '" + f + "' is not supported (ascii and binary_little_endian are)"; return false; }
         } else if (kw == "element") {
-            PlyElem e; ls >> e.name >> e.count; elems.push_back(e);
+            PlyElem e; long long cnt = -1;
+            if (!(ls >> e.name >> cnt) || cnt < 0) { err = "bad PLY element line: " + line; return false; }
+            e.count = (size_t)cnt; elems.push_back(e);
         } else if (kw == "property") {
             if (elems.empty()) { err = "PLY property before any element"; return false; }
             PlyProp p; std::string t; ls >> t;
@@ -147,6 +155,22 @@ bool load_ply(const char *path, uint32_t material, std::vector<kl_tri> &out, std
         } else if (kw == "end_header") break;
     }
     if (!have_format) { err = "PLY header has no format line"; return false; }
+    // Header counts are claims of the file: every element instance takes at least one byte per property (ascii: a
+    // digit and a separator share two), so a count beyond the bytes that remain, or an element without properties,
+    // cannot be honest. This also bounds the memory the loops below can ask for.
+    {
+        const std::streampos here = in.tellg();
+        in.seekg(0, std::ios::end);
+        const std::streampos end = in.tellg();
+        in.seekg(here);
+        const unsigned long long remain = (here >= 0 && end >= here) ? (unsigned long long)(end - here) : 0ull;
+        for (const PlyElem &e : elems) {
+            if (e.count == 0) continue;
+            if (e.props.empty()) { err = "PLY element '" + e.name + "' has a count but no properties"; return false; }
+            if ((unsigned long long)e.count > remain) { err = "PLY element count exceeds the size of the file"; return false; }
+            if ((e.name == "vertex" || e.name == "face") && e.count >= kMaxElements) { err = "PLY element count beyond 2^27"; return false; }
+        }
+    }
     std::vector<V3> v; std::vector<V2> vt;
     auto next_scalar = [&](PlyType t, double &val) -> bool {
         if (ascii) return (bool)(in >> val);
@@ -166,7 +190,11 @@ bool load_ply(const char *path, uint32_t material, std::vector<kl_tri> &out, std
                     const bool is_index = e.name == "face" && (pr.name == "vertex_indices" || pr.name == "vertex_index");
                     for (size_t k = 0; k < n; k++) {
                         if (!next_scalar(pr.type, val)) { err = "truncated PLY data"; return false; }
-                        if (is_index) idx.push_back((long)val);
+                        if (is_index) {
+                            // an index that is not a finite value inside the vertex array is rejected before the cast
+                            if (!(val >= 0.0 && val < (double)kMaxElements)) { err = "PLY face index out of range"; return false; }
+                            idx.push_back((long)val);
+                        }
                     }
                 } else {
                     if (!next_scalar(pr.type, val)) { err = "truncated PLY data"; return false; }
@@ -181,6 +209,7 @@ bool load_ply(const char *path, uint32_t material, std::vector<kl_tri> &out, std
             else if (e.name == "face") {
                 if (idx.size() < 3) { err = "PLY face with fewer than 3 corners"; return false; }
                 for (long k : idx) if (k < 0 || (size_t)k >= v.size()) { err = "PLY face index out of range"; return false; }
+                if (out.size() + idx.size() > kMaxTriangles) { err = "more than 2^25 triangles"; return false; }
                 for (size_t k = 1; k + 1 < idx.size(); k++) {
                     kl_tri tr;
                     put(tr, v[idx[0]], v[idx[k]], v[idx[k + 1]], vt[idx[0]], vt[idx[k]], vt[idx[k + 1]], material);
@@ -198,9 +227,7 @@ thread_local std::string g_mesh_error;
 
 extern "C" {
 
-kl_status kl_load_mesh(const char *path, uint32_t material, uint32_t n_materials, kl_tri **tris, uint32_t *n_tris) {
-    if (!path || !tris || !n_tris) return KL_E_INVALID;
-    *tris = nullptr; *n_tris = 0;
+static kl_status load_mesh_body(const char *path, uint32_t material, uint32_t n_materials, kl_tri **tris, uint32_t *n_tris) {
     std::vector<kl_tri> out;
     const std::string p(path);
     const size_t dot = p.find_last_of('.');
@@ -221,6 +248,16 @@ kl_status kl_load_mesh(const char *path, uint32_t material, uint32_t n_materials
     }
     *n_tris = (uint32_t)out.size();
     return KL_OK;
+}
+
+kl_status kl_load_mesh(const char *path, uint32_t material, uint32_t n_materials, kl_tri **tris, uint32_t *n_tris) {
+    if (!path || !tris || !n_tris) return KL_E_INVALID;
+    *tris = nullptr; *n_tris = 0;
+    // no exception crosses the C ABI (the loaders grow std::vectors from what a file claims)
+    try { return load_mesh_body(path, material, n_materials, tris, n_tris); }
+    catch (const std::bad_alloc &) { try { g_mesh_error = "host memory exhausted"; } catch (...) {} return KL_E_NOMEM; }
+    catch (const std::exception &e) { try { g_mesh_error = e.what(); } catch (...) {} return KL_E_INVALID; }
+    catch (...) { return KL_E_INVALID; }
 }
 
 const char *kl_load_mesh_error(void) { return g_mesh_error.c_str(); }

@@ -41,27 +41,49 @@ def reduce_samples(local_sum, n_frames_total, group=None):
     return local_sum
 
 
+def _device_of(renderer):
+    return torch.device("cuda", renderer.device)
+
+
 def render_tiles(renderer, n_frames, band_rows, first_frame=0, group=None):
     """Image-tile partition on the HIP path: shards `renderer` by row bands, renders, gathers."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     renderer.set_shard(rank, world, band_rows)
     renderer.render_frames(n_frames, first_frame=first_frame)
     rows = renderer.local_rows
-    local = torch.empty((rows, renderer.width, 4), dtype=torch.float32, device="cuda")
+    local = torch.empty((rows, renderer.width, 4), dtype=torch.float32, device=_device_of(renderer))
     if rows:
+        # the copy runs on the renderer's own stream and returns when it has landed; nothing of torch's is pending on `local`
         renderer.copy_accum_to_device(local.data_ptr(), local.numel() * 4)
     return gather_tiles(local, renderer.height, band_rows, group)
 
 
-def render_sample_ranges(renderer, n_frames, first_frame=0, group=None):
-    """Sample-range partition on the HIP path: every rank sums its frame range over the full image."""
+def live_frames(first_frame, n_frames, max_frames):
+    """frames of [first_frame, first_frame + n_frames) that are rendered, i.e. lie before the SAMPLES freeze
+    (RawFrame.glsl:426: a frame at or past SAMPLES repeats the accumulation and adds nothing to a sum)"""
+    if not max_frames:
+        return n_frames
+    return max(0, min(first_frame + n_frames, max_frames) - first_frame)
+
+
+def render_sample_ranges(renderer, n_frames, first_frame=0, group=None, out=None):
+    """Sample-range partition on the HIP path: every rank sums its frame range over the full image; returns the
+    mean over all ranks' frames. `out`: an (H, W, 4) float32 tensor on the renderer's device to reuse between calls."""
     from . import ACCUM_SUM
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi = partition.frame_range(first_frame, n_frames, rank, world)
     renderer.set_accum_mode(ACCUM_SUM)
     if hi > lo:
         renderer.render_frames(hi - lo, first_frame=lo)
-    local = torch.zeros((renderer.height, renderer.width, 4), dtype=torch.float32, device="cuda")
+    shape = (renderer.height, renderer.width, 4)
+    local = out if out is not None else torch.empty(shape, dtype=torch.float32, device=_device_of(renderer))
+    assert tuple(local.shape) == shape and local.dtype == torch.float32 and local.is_contiguous()
+    # `local` may still be read by the previous call's all_reduce / divide on torch's stream, and the copy below runs
+    # on the renderer's stream: wait for torch's side first
+    torch.cuda.current_stream(local.device).synchronize()
     if hi > lo:
         renderer.copy_accum_to_device(local.data_ptr(), local.numel() * 4)
-    return reduce_samples(local, n_frames, group)
+    else:
+        local.zero_()
+    live = live_frames(first_frame, n_frames, renderer.get_params().max_frames)
+    return reduce_samples(local, max(live, 1), group)

@@ -281,3 +281,57 @@ def test_random_soups_tree_equals_flat_loop_equals_oracle(counts):
     to, po, uo = oracle_trace(sc, o[:300], d[:300], 1)
     assert np.array_equal(np.where(po < 0, kl.MISS, po).astype(np.uint32), pf[:300])
     assert_bitexact(to, tf[:300], "t vs oracle"); assert_bitexact(uo, uf[:300], "uv vs oracle")
+
+
+def test_sum_accumulation_past_the_samples_freeze(small_scene, textures):
+    """KL_ACCUM_SUM with SAMPLES = 4: frames 4.. repeat the accumulation (RawFrame.glsl:426,461-463), so they add
+    nothing to the sum; sum / 4 equals the frozen running mean up to fp32 re-association, also for a call that starts
+    past the freeze (a rank whose sample range lies entirely behind it contributes zeros)."""
+    s, q, t, m = small_scene
+    w, h = 64, 36
+    with kl.Renderer(w, h) as r:
+        r.upload_scene(s, q, t, m)
+        r.upload_texture(kl.TEX_HDRI, textures["hdri"])
+        r.update_params(max_bounces=6, max_frames=4, frames_in_flight=3)
+        r.render_frames(9)
+        mean = r.read_accum()
+        r.set_accum_mode(kl.ACCUM_SUM)
+        r.render_frames(9, first_frame=0)          # batches 3 + 1 traced, then five frozen frames
+        total = r.read_accum()
+        r.set_accum_mode(kl.ACCUM_SUM)
+        r.render_frames(3, first_frame=6)          # wholly behind the freeze
+        nothing = r.read_accum()
+    sc = ko.Scene(s, q, t, m)
+    sc.set_texture(ko.TEX_HDRI, textures["hdri"])
+    want = ko.render_mean(sc, ko.default_camera(), ko.default_params(width=w, height=h, mode=ko.MODE_PT, max_frames=4,
+                                                                     max_bounces=6, use_bvh=1), 9)
+    assert_bitexact(mean, want, "frozen running mean vs oracle")
+    assert np.allclose(total[..., :3] / 4.0, want[..., :3], rtol=2e-6, atol=1e-7)
+    assert not nothing[..., :3].any()
+
+
+def test_trace_rays_tie_between_a_flat_quad_and_a_tree_quad_keeps_the_uv():
+    """A wall-sized quad (kept out of the tree, found by the flat pass) and a small coplanar quad declared after it (in
+    the tree): equal t, the lower declaration-order id wins as in the shader's in-order loop (RawFrame.glsl:316), and
+    the winner's (u, v) must survive the traversal that met the tie."""
+    quads = np.zeros(2, dtype=kl.quad_dtype)
+    quads[0]["v0"], quads[0]["v1"], quads[0]["v2"], quads[0]["v3"] = (-8, -8, 0), (8, -8, 0), (8, 8, 0), (-8, 8, 0)
+    quads[1]["v0"], quads[1]["v1"], quads[1]["v2"], quads[1]["v3"] = (-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)
+    rng = np.random.default_rng(5)
+    # enough small triangles elsewhere that a tree is built and the big quad counts as scene-spanning
+    tris = np.zeros(200, dtype=kl.tri_dtype)
+    c = rng.uniform(-6, 6, (200, 3)).astype(np.float32); c[:, 2] = rng.uniform(-6, -1, 200)
+    tris["v0"] = c; tris["v1"] = c + np.float32([0.1, 0, 0]); tris["v2"] = c + np.float32([0, 0.1, 0])
+    mats = np.zeros(1, dtype=kl.material_dtype); mats["color"] = 1
+    o = np.zeros((256, 3), np.float32); o[:, 0] = rng.uniform(-0.9, 0.9, 256); o[:, 1] = rng.uniform(-0.9, 0.9, 256); o[:, 2] = 3
+    d = np.tile(np.float32([0, 0, -1]), (256, 1))
+    with kl.Renderer(16, 16) as r:
+        r.update_params(accel=kl.ACCEL_BVH)
+        r.upload_scene(None, quads, tris, mats)
+        st = r.bvh_stats()
+        assert st.flat_quads == 1
+        t_bvh, p_bvh, uv_bvh = r.trace_rays(o, d)
+        r.update_params(accel=kl.ACCEL_BRUTE)
+        t_ref, p_ref, uv_ref = r.trace_rays(o, d)
+    assert (p_ref == 0).all() and np.array_equal(p_bvh, p_ref) and np.array_equal(t_bvh, t_ref)
+    assert np.array_equal(uv_bvh, uv_ref) and uv_ref.any()

@@ -87,3 +87,47 @@ def test_ply_ascii_and_binary_agree(tmp_path):
     d.write_bytes(blob[:-6])
     with pytest.raises(kl.KlError, match="truncated"):
         kl.load_mesh(str(d))
+
+
+def _expect_refused(path, needle=None):
+    with pytest.raises(kl.KlError) as ei:
+        kl.load_mesh(str(path))
+    if needle:
+        assert needle in str(ei.value)
+
+
+def test_ply_header_counts_are_checked_against_the_file(tmp_path):
+    """a header may claim any count: the loader must answer with a status, not loop or exhaust memory"""
+    p = tmp_path / "huge.ply"
+    p.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 1000000000000000000\nend_header\n")
+    _expect_refused(p, "no properties")
+    p.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 1000000000000000000\nproperty float x\nend_header\n\0\0\0\0")
+    _expect_refused(p, "exceeds the size")
+    p.write_bytes(b"ply\nformat ascii 1.0\nelement vertex -5\nproperty float x\nend_header\n")
+    _expect_refused(p, "bad PLY element")
+    # face index that is NaN / far out of range
+    p.write_bytes(b"ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+                  b"element face 1\nproperty list uchar float vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 nan 2\n")
+    _expect_refused(p)            # the stream refuses "nan" as a number: reported as truncated data
+    p.write_bytes(b"ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+                  b"element face 1\nproperty list uchar double vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1e300 2\n")
+    _expect_refused(p, "out of range")
+
+
+def test_garbage_and_truncated_files_are_refused(tmp_path):
+    rng = np.random.default_rng(11)
+    for k in range(20):
+        p = tmp_path / ("g%d.ply" % k)
+        p.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 40\nproperty float x\nproperty float y\nproperty float z\n"
+                      b"element face 30\nproperty list uchar int vertex_indices\nend_header\n" + rng.bytes(int(rng.integers(0, 900))))
+        try:
+            kl.load_mesh(str(p))
+        except kl.KlError:
+            pass
+    for k in range(20):
+        p = tmp_path / ("g%d.obj" % k)
+        p.write_bytes(b"v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n" + rng.bytes(int(rng.integers(0, 400))))
+        try:
+            kl.load_mesh(str(p))
+        except kl.KlError:
+            pass
