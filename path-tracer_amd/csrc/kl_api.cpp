@@ -1,10 +1,12 @@
 // C-ABI implementation (include/Math/kl_render.h): context, uploads, the frame
 // loop that sequences the wavefront kernels on one HIP stream, read-back.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <new>
 #include <string>
@@ -114,6 +116,15 @@ struct kl_ctx {
 namespace {
 
 kl_status fail(kl_ctx *c, kl_status s, const std::string &msg) { if (c) c->err = msg; return s; }
+
+// No exception crosses the C ABI: host-side allocations (std::vector, std::string) of an entry point's body are
+// turned into a status here.
+template <typename F> kl_status guarded(kl_ctx *c, F body) noexcept {
+    try { return body(); }
+    catch (const std::bad_alloc &) { try { if (c) c->err = "host memory exhausted"; } catch (...) {} return KL_E_NOMEM; }
+    catch (const std::exception &e) { try { if (c) c->err = e.what(); } catch (...) {} return KL_E_INVALID; }
+    catch (...) { return KL_E_INVALID; }
+}
 
 #define KL_HIP(ctx, call)                                                                          \
     do {                                                                                           \
@@ -417,7 +428,7 @@ kl_status kl_default_camera(kl_camera *cam) {
     return KL_OK;
 }
 
-kl_status kl_create(kl_ctx **out, int32_t device, uint32_t width, uint32_t height) {
+static kl_status kl_create_body(kl_ctx **out, int32_t device, uint32_t width, uint32_t height) {
     if (!out) return KL_E_INVALID;
     *out = nullptr;
     if (width == 0 || height == 0 || width > KL_MAX_DIM || height > KL_MAX_DIM) return KL_E_INVALID;
@@ -452,6 +463,9 @@ kl_status kl_create(kl_ctx **out, int32_t device, uint32_t width, uint32_t heigh
     if (s == KL_OK) s = kl_upload_texture(c, KL_TEX_ALBEDO, white, 1, 1, 4);
     if (s != KL_OK) { kl_destroy(c); *out = nullptr; }
     return s;
+}
+kl_status kl_create(kl_ctx **out, int32_t device, uint32_t width, uint32_t height) {
+    return guarded(nullptr, [&]() { return kl_create_body(out, device, width, height); });
 }
 
 kl_status kl_destroy(kl_ctx *c) {
@@ -523,7 +537,7 @@ kl_status kl_set_params(kl_ctx *c, const kl_params *p) {
 }
 kl_status kl_get_params(kl_ctx *c, kl_params *p) { if (!c || !p) return KL_E_INVALID; *p = c->params; return KL_OK; }
 
-kl_status kl_upload_texture(kl_ctx *c, uint32_t which, const uint8_t *px, uint32_t w, uint32_t h, uint32_t ch) {
+static kl_status kl_upload_texture_body(kl_ctx *c, uint32_t which, const uint8_t *px, uint32_t w, uint32_t h, uint32_t ch) {
     if (!c || which > KL_TEX_ALBEDO || !px || !w || !h || w > KL_MAX_DIM || h > KL_MAX_DIM || (ch != 1 && ch != 3 && ch != 4))
         return fail(c, KL_E_INVALID, "texture must be 8-bit with 1, 3 or 4 channels");
     KL_HIP(c, hipSetDevice(c->device));
@@ -540,8 +554,11 @@ kl_status kl_upload_texture(kl_ctx *c, uint32_t which, const uint8_t *px, uint32
     c->sc.tex[which] = c->d_tex[which].p; c->sc.tex_w[which] = w; c->sc.tex_h[which] = h;
     return KL_OK;
 }
+kl_status kl_upload_texture(kl_ctx *c, uint32_t which, const uint8_t *px, uint32_t w, uint32_t h, uint32_t ch) {
+    return guarded(c, [&]() { return kl_upload_texture_body(c, which, px, w, h, ch); });
+}
 
-kl_status kl_upload_env_float(kl_ctx *c, const float *px, uint32_t w, uint32_t h, uint32_t ch) {
+static kl_status kl_upload_env_float_body(kl_ctx *c, const float *px, uint32_t w, uint32_t h, uint32_t ch) {
     if (!c) return KL_E_INVALID;
     KL_HIP(c, hipSetDevice(c->device));
     KL_HIP(c, hipStreamSynchronize(c->stream));
@@ -559,8 +576,11 @@ kl_status kl_upload_env_float(kl_ctx *c, const float *px, uint32_t w, uint32_t h
     c->sc.envf = c->d_envf.p; c->sc.envf_w = w; c->sc.envf_h = h;
     return kl_reset(c);
 }
+kl_status kl_upload_env_float(kl_ctx *c, const float *px, uint32_t w, uint32_t h, uint32_t ch) {
+    return guarded(c, [&]() { return kl_upload_env_float_body(c, px, w, h, ch); });
+}
 
-kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq,
+static kl_status kl_upload_scene_body(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq,
                           const kl_tri *t, uint32_t nt, const kl_material *m, uint32_t nm) {
     if (!c || (ns && !s) || (nq && !q) || (nt && !t) || !m || nm == 0) return fail(c, KL_E_INVALID, "null scene array");
     if ((uint64_t)ns + nq + nt >= MAX_RECORDS / 2)
@@ -702,14 +722,21 @@ kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_q
     c->have_scene = true;
     return kl_reset(c);
 }
+kl_status kl_upload_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq,
+                          const kl_tri *t, uint32_t nt, const kl_material *m, uint32_t nm) {
+    return guarded(c, [&]() { return kl_upload_scene_body(c, s, ns, q, nq, t, nt, m, nm); });
+}
 
-kl_status kl_load_builtin_scene(kl_ctx *c) {
+static kl_status kl_load_builtin_scene_body(kl_ctx *c) {
     if (!c) return KL_E_INVALID;
     std::vector<kl_sphere> s; std::vector<kl_quad> q; std::vector<kl_material> m;
     builtin_scene(s, q, m);
     return kl_upload_scene(c, s.data(), (uint32_t)s.size(), q.data(), (uint32_t)q.size(), nullptr, 0, m.data(), (uint32_t)m.size());
 }
-kl_status kl_refit_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt) {
+kl_status kl_load_builtin_scene(kl_ctx *c) {
+    return guarded(c, [&]() { return kl_load_builtin_scene_body(c); });
+}
+static kl_status kl_refit_scene_body(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt) {
     if (!c || (ns && !s) || (nq && !q) || (nt && !t)) return fail(c, KL_E_INVALID, "null scene array");
     if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");
     if (ns != c->sc.count[PRIM_SPHERE] || nq != c->sc.count[PRIM_QUAD] || nt != c->sc.count[PRIM_TRI])
@@ -728,6 +755,9 @@ kl_status kl_refit_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_qu
     c->bvh_stats.refit_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return kl_reset(c);
 }
+kl_status kl_refit_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt) {
+    return guarded(c, [&]() { return kl_refit_scene_body(c, s, ns, q, nq, t, nt); });
+}
 kl_status kl_get_bvh_stats(kl_ctx *c, kl_bvh_stats *out) {
     if (!c || !out) return KL_E_INVALID;
     if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");
@@ -740,7 +770,7 @@ kl_status kl_synth_scene_counts(const kl_synth_params *sp, uint32_t *ns, uint32_
     synth_counts(*sp, *ns, *nq, *nt, *nm);
     return KL_OK;
 }
-kl_status kl_synth_scene_fill(const kl_synth_params *sp, kl_sphere *s, kl_quad *q, kl_tri *t, kl_material *m) {
+static kl_status kl_synth_scene_fill_body(const kl_synth_params *sp, kl_sphere *s, kl_quad *q, kl_tri *t, kl_material *m) {
     uint32_t ns, nq, nt, nm;
     kl_status st = kl_synth_scene_counts(sp, &ns, &nq, &nt, &nm);
     if (st != KL_OK) return st;
@@ -748,8 +778,11 @@ kl_status kl_synth_scene_fill(const kl_synth_params *sp, kl_sphere *s, kl_quad *
     synth_fill(*sp, s, q, t, m);
     return KL_OK;
 }
+kl_status kl_synth_scene_fill(const kl_synth_params *sp, kl_sphere *s, kl_quad *q, kl_tri *t, kl_material *m) {
+    return guarded(nullptr, [&]() { return kl_synth_scene_fill_body(sp, s, q, t, m); });
+}
 
-kl_status kl_render_frames(kl_ctx *c, uint32_t n, uint32_t first_frame) {
+static kl_status kl_render_frames_body(kl_ctx *c, uint32_t n, uint32_t first_frame) {
     if (!c) return KL_E_INVALID;
     if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");
     if (c->npl == 0 || n == 0) return KL_OK;
@@ -789,7 +822,17 @@ kl_status kl_render_frames(kl_ctx *c, uint32_t n, uint32_t first_frame) {
         } else {
             k = std::min(left, std::min(per_batch, c->slots));
             if (mf) k = std::min(k, mf - frame);
-            if ((s = render_batch(c, L, after, frame, k, c->camera_change)) != KL_OK) return s;
+            if ((s = render_batch(c, L, after, frame, k, c->camera_change)) != KL_OK) {
+                // the context stream still resumes after whatever the lanes were given, and the call's events go back
+                // (best effort: the error that is reported is the first one)
+                lane_used[l] = true;
+                for (uint32_t j = 1; j < lanes; j++)
+                    if (lane_used[j] && hipEventRecord(c->lanes[j].done, c->lanes[j].stream) == hipSuccess)
+                        (void)hipStreamWaitEvent(c->stream, c->lanes[j].done, 0);
+                if (ea) c->free_events.push_back(ea);
+                if (eb) c->free_events.push_back(eb);
+                return s;
+            }
             c->paths_total += (uint64_t)k * c->npl;
         }
         if (lanes > 1) { KL_HIP(c, hipEventRecord(L.done, L.stream)); last_done = L.done; }
@@ -804,6 +847,9 @@ kl_status kl_render_frames(kl_ctx *c, uint32_t n, uint32_t first_frame) {
     c->frame = frame;                   // iFrame++ per frame, GLSL_Renderer.cpp:347
     if (ea && eb) { KL_HIP(c, hipEventRecord(eb, c->stream)); c->pending.push_back({ea, eb, 1}); }
     return KL_OK;
+}
+kl_status kl_render_frames(kl_ctx *c, uint32_t n, uint32_t first_frame) {
+    return guarded(c, [&]() { return kl_render_frames_body(c, n, first_frame); });
 }
 
 kl_status kl_synchronize(kl_ctx *c) {
@@ -851,7 +897,7 @@ kl_status kl_get_counters(kl_ctx *c, kl_counters *out) {
     }
     return KL_OK;
 }
-kl_status kl_reset_counters(kl_ctx *c) {
+static kl_status kl_reset_counters_body(kl_ctx *c) {
     if (!c) return KL_E_INVALID;
     KL_HIP(c, hipSetDevice(c->device));
     c->frames_total = 0; c->paths_total = 0;
@@ -860,15 +906,21 @@ kl_status kl_reset_counters(kl_ctx *c) {
     if (c->d_counters.p) KL_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream));
     return KL_OK;
 }
-kl_status kl_get_timing(kl_ctx *c, kl_timing *out) {
+kl_status kl_reset_counters(kl_ctx *c) {
+    return guarded(c, [&]() { return kl_reset_counters_body(c); });
+}
+static kl_status kl_get_timing_body(kl_ctx *c, kl_timing *out) {
     if (!c || !out) return KL_E_INVALID;
     KL_HIP(c, hipSetDevice(c->device));
     drain_events(c);
     *out = c->timing;
     return KL_OK;
 }
+kl_status kl_get_timing(kl_ctx *c, kl_timing *out) {
+    return guarded(c, [&]() { return kl_get_timing_body(c, out); });
+}
 
-kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, float *t, uint32_t *prim, float *uv) {
+static kl_status kl_trace_rays_body(kl_ctx *c, const float *o, const float *d, uint32_t n, float *t, uint32_t *prim, float *uv) {
     if (!c || !o || !d || !t || !prim || !uv) return fail(c, KL_E_INVALID, "null ray arrays");
     if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");
     if (n == 0) return KL_OK;
@@ -910,6 +962,9 @@ kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, f
     KL_HIP(c, hipStreamSynchronize(c->stream));
     KL_HIP(c, hipGetLastError());
     return KL_OK;
+}
+kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, float *t, uint32_t *prim, float *uv) {
+    return guarded(c, [&]() { return kl_trace_rays_body(c, o, d, n, t, prim, uv); });
 }
 
 kl_status kl_set_shard(kl_ctx *c, uint32_t rank, uint32_t world, uint32_t band_rows) {
@@ -959,7 +1014,7 @@ struct CkHeader {
 };
 }  // namespace
 
-kl_status kl_checkpoint_save(kl_ctx *c, const char *path) {
+static kl_status kl_checkpoint_save_body(kl_ctx *c, const char *path) {
     if (!c || !path) return fail(c, KL_E_INVALID, "null path");
     if (!c->d_acc.p || c->d_acc.n != c->npl || !c->npl) return fail(c, KL_E_STATE, "nothing rendered yet");
     KL_HIP(c, hipSetDevice(c->device));
@@ -979,8 +1034,11 @@ kl_status kl_checkpoint_save(kl_ctx *c, const char *path) {
     ok = (std::fclose(fp) == 0) && ok;
     return ok ? KL_OK : fail(c, KL_E_INVALID, std::string("short write to ") + path);
 }
+kl_status kl_checkpoint_save(kl_ctx *c, const char *path) {
+    return guarded(c, [&]() { return kl_checkpoint_save_body(c, path); });
+}
 
-kl_status kl_checkpoint_load(kl_ctx *c, const char *path) {
+static kl_status kl_checkpoint_load_body(kl_ctx *c, const char *path) {
     if (!c || !path) return fail(c, KL_E_INVALID, "null path");
     FILE *fp = std::fopen(path, "rb");
     if (!fp) return fail(c, KL_E_INVALID, std::string("cannot read ") + path);
@@ -1009,6 +1067,9 @@ kl_status kl_checkpoint_load(kl_ctx *c, const char *path) {
     c->cam = hd.cam; c->mode = hd.mode; c->accum_mode = hd.accum_mode;
     c->frame = hd.frame; c->camera_change = hd.camera_change != 0;
     return KL_OK;
+}
+kl_status kl_checkpoint_load(kl_ctx *c, const char *path) {
+    return guarded(c, [&]() { return kl_checkpoint_load_body(c, path); });
 }
 
 }  // extern "C"

@@ -113,7 +113,10 @@ __device__ __forceinline__ bool tri_intersect(v3 o, v3 d, v3 v0, v3 e1, v3 e2, f
     return true;
 }
 
-struct Hit { float t; uint32_t ref; float u, v; uint32_t id; uint32_t uvf; };   // uvf: the primitive's uv flag (shading reads u, v)
+// uvf: bit 0 = the primitive's uv flag (shading reads u, v); bit 1 = this hit was taken by accept() (as opposed to
+// handed over from a queue entry)
+struct Hit { float t; uint32_t ref; float u, v; uint32_t id; uint32_t uvf; };
+constexpr uint32_t HIT_UV = 1u, HIT_TAKEN = 2u;
 
 // declaration-order id of a primitive reference (read from its record)
 __device__ __forceinline__ uint32_t ref_id(const SceneDev &sc, uint32_t ref) {
@@ -134,7 +137,7 @@ __device__ __forceinline__ void accept(Hit &h, float t, uint32_t ref, uint32_t i
         if (lazy && h.id == ID_UNKNOWN) h.id = ref_id(*lazy, h.ref);
         take = id < h.id;
     }
-    if (take) { h.t = t; h.ref = ref; h.id = id; h.u = u; h.v = v; h.uvf = uvf; }
+    if (take) { h.t = t; h.ref = ref; h.id = id; h.u = u; h.v = v; h.uvf = uvf | HIT_TAKEN; }
 }
 // primitive tests on the 64-byte records of kl_types.hpp
 __device__ __forceinline__ void test_sphere(float4 r0, float4 r1, uint32_t i, v3 o, v3 d, float eps, Hit &h, const SceneDev *lazy = nullptr) {
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) void k_generate(SceneDev sc, FrameDev f, RayQu
         } else if (flat) {
             const Hit h = flat_hit(sc, f, pos, d);
             t = h.t; ref = h.ref;
-            if (h.uvf) q.uv[dst] = make_float2(h.u, h.v);
+            if (h.uvf & HIT_UV) q.uv[dst] = make_float2(h.u, h.v);
         }
         q.od[dst] = make_float4(pos.x, pos.y, pos.z, d.x);
         q.dt[dst] = make_float4(d.y, d.z, t, __uint_as_float(ref));
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void k_generate(SceneDev sc, FrameDev f, RayQu
 // the two words of a queue entry that hold the closest hit, and the (u, v) of hits whose shading reads them
 __device__ __forceinline__ void store_hit(const RayQueue &q, uint32_t i, const Hit &h) {
     ((float2 *)(q.dt + i))[1] = make_float2(h.t, __uint_as_float(h.ref));
-    if (h.uvf) q.uv[i] = make_float2(h.u, h.v);
+    if (h.uvf & HIT_UV) q.uv[i] = make_float2(h.u, h.v);
 }
 
 // ------------------------------------------------------------------ intersect: flat loop
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256) void k_intersect_brute(SceneDev sc, FrameDev f
             test_range(sc, PRIM_QUAD, sc.base[PRIM_QUAD], sc.count[PRIM_QUAD], o, d, f.eps, h);
             test_range(sc, PRIM_TRI, sc.base[PRIM_TRI], sc.count[PRIM_TRI], o, d, f.eps, h);
         }
-        if (f.all_uv) h.uvf = 1u;
+        if (f.all_uv) h.uvf |= HIT_UV;
         store_hit(q, i, h);
     }
 }
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(256) void k_intersect_flat(SceneDev sc, FrameDev f,
         const uint32_t i = seg * f.segcap + r;
         float4 od = q.od[i]; float4 dt = q.dt[i];
         Hit h = flat_hit(sc, f, V(od.x, od.y, od.z), V(od.w, dt.x, dt.y));
-        if (f.all_uv) h.uvf = 1u;
+        if (f.all_uv) h.uvf |= HIT_UV;
         store_hit(q, i, h);
     }
 }
@@ -563,13 +566,13 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                         sp--;
                         node = top;
                     } else {
-                        // A ray that met nothing closer in the tree leaves its entry as it is: h.id is still one of the two
-                        // values it started with (accept() stores a real id with every hit it takes). The address is
-                        // formed here, from the ray index, rather than carried through the loop in two registers.
-                        if (h.id < ID_UNKNOWN) {
+                        // A ray that met nothing closer in the tree leaves its entry as it is (accept() marks every hit it
+                        // takes; an exact tie that the entry's own hit wins fetches that hit's id but takes nothing). The
+                        // address is formed here, from the ray index, rather than carried through the loop in two registers.
+                        if (h.uvf & HIT_TAKEN) {
                             uint32_t slot = ray;
                             asm volatile("" : "+v"(slot));
-                            if (f.all_uv) h.uvf = 1u;
+                            if (f.all_uv) h.uvf |= HIT_UV;
                             store_hit(q, slot, h);
                         }
                         active = false;
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(256, KL_SHADE_MIN_WAVES) void k_shade(SceneDev sc_b
                     qout.od[slot_out] = make_float4(o.x, o.y, o.z, d.x);
                     qout.dt[slot_out] = make_float4(d.y, d.z, fh.t, __uint_as_float(fh.ref));
                     qout.tp[slot_out] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(path));
-                    if (fh.uvf) qout.uv[slot_out] = make_float2(fh.u, fh.v);
+                    if (fh.uvf & HIT_UV) qout.uv[slot_out] = make_float2(fh.u, fh.v);
                 }
             }
         } else if (valid) {
@@ -869,7 +872,9 @@ __global__ __launch_bounds__(256) void k_accumulate(FrameDev f, const float4 *ra
             const bool frozen = f.max_frames != 0u && frame >= f.max_frames;
             r = frozen ? a : raw[(size_t)s * f.npl + li];
             if (accum_mode == KL_ACCUM_SUM) {
-                a.x += r.x; a.y += r.y; a.z += r.z; a.w = 1.0f;
+                // a frozen frame leaves the mean where it is, i.e. adds no term to the sum
+                if (!frozen) { a.x += r.x; a.y += r.y; a.z += r.z; }
+                a.w = 1.0f;
             } else if (frame <= 1u || !(camera_change && s == 0u)) {
                 float w = (float)frame;
                 a.x = (a.x * w + r.x) / (w + 1.0f);

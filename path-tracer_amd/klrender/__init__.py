@@ -195,7 +195,7 @@ class Renderer:
         rc = lib().kl_create(C.byref(self._h), device, width, height)
         if rc != 0:
             raise KlError("kl_create failed: %s" % lib().kl_status_string(rc).decode())
-        self.width, self.height = width, height
+        self.width, self.height, self.device = width, height, device
 
     # -- plumbing
     def _ck(self, rc, what):
