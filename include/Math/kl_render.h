@@ -230,6 +230,19 @@ KL_API kl_status kl_get_timing(kl_ctx *ctx, kl_timing *out);
 KL_API kl_status kl_trace_rays(kl_ctx *ctx, const float *o, const float *d, uint32_t n,
                                float *t, uint32_t *prim, float *uv);
 
+/* One entry point that allocates nothing. It has no counterpart in the reference; it is kl_trace_rays for callers that
+ * cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * All pointers are DEVICE pointers on the context's device (o, d: n x 3 floats; t: n; prim: n; uv: n x 2 floats).
+ * The queue entries, counters and traversal stack spill that kl_trace_rays allocates per call live in a fixed
+ * device array of the library instead (about 33 MB per GPU, held until the process ends), hence the limit:
+ * n <= KL_NOALLOC_MAX_RAYS, else KL_E_LIMIT. The work is queued on the context's stream and the call returns without
+ * waiting (kl_synchronize waits). Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two
+ * contexts, two threads) race; calls on one context are ordered by its stream. Same hits as kl_trace_rays, bit for
+ * bit; rays traced here are not tallied by kl_get_counters. */
+#define KL_NOALLOC_MAX_RAYS 262144u
+KL_API kl_status kl_trace_rays_noalloc(kl_ctx *ctx, const float *o_dev, const float *d_dev, uint32_t n,
+                                       float *t_dev, uint32_t *prim_dev, float *uv_dev);
+
 /* -- partitioning over GPUs (no reference counterpart). Image tiles: this context renders the
  *    row bands b with b % world == rank, band_rows rows each; its buffers then hold only those
  *    rows, in increasing row order. Sample ranges: use KL_ACCUM_SUM and disjoint first_frame ranges. -- */

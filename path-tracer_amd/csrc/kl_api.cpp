@@ -440,6 +440,7 @@ static kl_status kl_create_body(kl_ctx **out, int32_t device, uint32_t width, ui
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c; return KL_E_DEVICE;
     }
+    if (noalloc_init(device) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return KL_E_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->lc.cus = (uint32_t)prop.multiProcessorCount;
 #ifndef KL_ISECT_BLOCKS_PER_CU
@@ -965,6 +966,23 @@ static kl_status kl_trace_rays_body(kl_ctx *c, const float *o, const float *d, u
 }
 kl_status kl_trace_rays(kl_ctx *c, const float *o, const float *d, uint32_t n, float *t, uint32_t *prim, float *uv) {
     return guarded(c, [&]() { return kl_trace_rays_body(c, o, d, n, t, prim, uv); });
+}
+
+// kl_trace_rays for callers that cannot allocate: device pointers in and out, intermediate storage in the library's
+// fixed device array (kl_kernels.hip), no hipMalloc / hipFree and no host container on the way.
+kl_status kl_trace_rays_noalloc(kl_ctx *c, const float *o, const float *d, uint32_t n, float *t, uint32_t *prim, float *uv) {
+    if (!c) return KL_E_INVALID;
+    if (!o || !d || !t || !prim || !uv) { c->err = "null ray arrays"; return KL_E_INVALID; }
+    if (!c->have_scene) { c->err = "no scene uploaded"; return KL_E_STATE; }
+    if (n == 0) return KL_OK;
+    if (n > KL_NOALLOC_MAX_RAYS) { c->err = "kl_trace_rays_noalloc takes at most KL_NOALLOC_MAX_RAYS (262144) rays per call"; return KL_E_LIMIT; }
+    if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice"; return KL_E_DEVICE; }
+    FrameDev f = make_frame(c, 0, 1);
+    f.nseg = 1; f.segcap = n;                       // caller rays form one segment
+    f.all_uv = 1;                                   // (u, v) of every hit, whatever its material
+    const hipError_t e = launch_trace_noalloc(c->stream, c->device, c->lc, c->sc, f, o, d, n, t, prim, (float2 *)uv, use_bvh(c));
+    if (e != hipSuccess) { c->err = hipGetErrorString(e); return KL_E_DEVICE; }
+    return KL_OK;
 }
 
 kl_status kl_set_shard(kl_ctx *c, uint32_t rank, uint32_t world, uint32_t band_rows) {

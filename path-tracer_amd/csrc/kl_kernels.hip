@@ -1007,4 +1007,70 @@ void launch_unpack_hits(hipStream_t s, const SceneDev &sc, RayQueue q, uint32_t 
     hipLaunchKernelGGL(k_unpack_hits, dim3((n + 255u) / 256u), dim3(256), 0, s, sc, q, n, t, prim, uv);
 }
 
+// ------------------------------------------------------------------ closest hits without any allocation
+// kl_trace_rays_noalloc: the queue entries, the segment counters, the traversal's stack overflow slab and a
+// Counters block live in one file-scope device array instead of buffers allocated per call. Every GPU the library
+// runs on holds its own copy of the array (at its own address) until the process ends; calls on one GPU share it.
+constexpr uint32_t NOALLOC_BLOCKS = 256;                       // traversal workgroups of a no-allocation launch
+constexpr size_t NOALLOC_OD = 0;                                // float4[MAX]
+constexpr size_t NOALLOC_DT = NOALLOC_OD + (size_t)KL_NOALLOC_MAX_RAYS * 16;
+constexpr size_t NOALLOC_UV = NOALLOC_DT + (size_t)KL_NOALLOC_MAX_RAYS * 16;   // float2[MAX]
+constexpr size_t NOALLOC_CTL = NOALLOC_UV + (size_t)KL_NOALLOC_MAX_RAYS * 8;   // count, head: CTR_STRIDE words apart
+constexpr size_t NOALLOC_CN = NOALLOC_CTL + 2 * CTR_STRIDE * 4;                // Counters
+constexpr size_t NOALLOC_OVF = NOALLOC_CN + 256;                               // stack entries beyond the LDS part
+constexpr size_t NOALLOC_BYTES = NOALLOC_OVF + (size_t)NOALLOC_BLOCKS * ISECT_WAVES * ISECT_OVF_STACK * 64u * 4u;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static unsigned char *g_scratch_ptr[NOALLOC_MAX_DEVICES];      // device address of `scratch` on each GPU, set once per device
+
+size_t noalloc_scratch_bytes() { return NOALLOC_BYTES; }
+
+// With `device` current: looks up the address of this GPU's copy of `scratch` (the array's name is a host-side
+// stand-in, not a device address) and keeps it. Called from kl_create, i.e. once per context; cheap when already known.
+hipError_t noalloc_init(int device) {
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (__atomic_load_n(&g_scratch_ptr[device], __ATOMIC_ACQUIRE)) return hipSuccess;
+    unsigned char *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    __atomic_store_n(&g_scratch_ptr[device], ptr, __ATOMIC_RELEASE);
+    return hipSuccess;
+}
+
+// caller rays (n x 3 floats each) -> queue entries that start as misses; also the segment's count / head and the
+// counters block, so that nothing of the previous call is left where this one reads
+__global__ __launch_bounds__(256) void k_pack_rays(const float *o, const float *d, uint32_t n, RayQueue q, uint32_t *ctl, Counters *cn,
+                                                   float max_dist) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        ctl[0] = n; ctl[CTR_STRIDE] = 0u;
+        Counters z; memset(&z, 0, sizeof z); *cn = z;
+    }
+    if (i >= n) return;
+    q.od[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i]);
+    q.dt[i] = make_float4(d[3 * i + 1], d[3 * i + 2], max_dist, __uint_as_float(REF_MISS));
+    q.uv[i] = make_float2(0.0f, 0.0f);
+}
+
+// o, d, t, prim, uv: device pointers. f: a frame description with nseg = 1, segcap = n, all_uv = 1.
+hipError_t launch_trace_noalloc(hipStream_t s, int device, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, const float *o,
+                                const float *d, uint32_t n, float *t, uint32_t *prim, float2 *uv, bool bvh) {
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES || n == 0 || n > KL_NOALLOC_MAX_RAYS || f.nseg != 1u || f.segcap < n) return hipErrorInvalidValue;
+    unsigned char *base = __atomic_load_n(&g_scratch_ptr[device], __ATOMIC_ACQUIRE);
+    if (!base) return hipErrorNotInitialized;
+    RayQueue q = { (float4 *)(base + NOALLOC_OD), (float4 *)(base + NOALLOC_DT), nullptr, (float2 *)(base + NOALLOC_UV) };
+    uint32_t *ctl = (uint32_t *)(base + NOALLOC_CTL);
+    Counters *cn = (Counters *)(base + NOALLOC_CN);
+    int *ovf = (int *)(base + NOALLOC_OVF);
+    hipLaunchKernelGGL(k_pack_rays, dim3((n + 255u) / 256u), dim3(256), 0, s, o, d, n, q, ctl, cn, f.max_dist);
+    if (bvh && scene_has_flat(sc)) launch_intersect_flat(s, lc, sc, f, q, ctl, cn, false, n);
+    LaunchCfg small = lc;                       // the overflow slab in `scratch` is sized for NOALLOC_BLOCKS workgroups
+    small.cus = NOALLOC_BLOCKS; small.isect_blocks_per_cu = 1;
+    launch_intersect(s, small, sc, f, q, ctl, ctl + CTR_STRIDE, cn, ovf, bvh, false, n);
+    launch_unpack_hits(s, sc, q, n, t, prim, uv);
+    return hipGetLastError();
+}
+
 }  // namespace kl

@@ -38,4 +38,11 @@ void launch_accumulate(hipStream_t s, const LaunchCfg &lc, const FrameDev &f, co
 void launch_resolve(hipStream_t s, const LaunchCfg &lc, const float4 *acc, uchar4 *out, uint32_t n, uint32_t tonemap);
 void launch_unpack_hits(hipStream_t s, const SceneDev &sc, RayQueue q, uint32_t n, float *t, uint32_t *prim, float2 *uv);
 
+// closest hits for caller rays without allocating anything: all intermediate storage is a file-scope device array
+// (kl_kernels.hip). noalloc_init(device), with that device current, once per device before the first launch.
+hipError_t noalloc_init(int device);
+size_t noalloc_scratch_bytes();
+hipError_t launch_trace_noalloc(hipStream_t s, int device, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, const float *o,
+                                const float *d, uint32_t n, float *t, uint32_t *prim, float2 *uv, bool bvh);
+
 }  // namespace kl

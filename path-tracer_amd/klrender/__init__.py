@@ -24,6 +24,7 @@ ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
 BUILD_HOST_SAH, BUILD_GPU_LBVH = 0, 1
 CONTINUE = 0xFFFFFFFF
 MISS = 0xFFFFFFFF
+NOALLOC_MAX_RAYS = 262144
 
 material_dtype = np.dtype([("type", "<i4"), ("color", "<f4", 3), ("emissive", "<f4"),
                            ("roughness", "<f4"), ("ior", "<f4"), ("pad", "<f4")])
@@ -99,6 +100,7 @@ SIGNATURES = {
     "kl_reset_counters": (C.c_int32, [_P]),
     "kl_get_timing": (C.c_int32, [_P, C.POINTER(Timing)]),
     "kl_trace_rays": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _P]),
+    "kl_trace_rays_noalloc": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _P]),
     "kl_set_shard": (C.c_int32, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "kl_get_local_rows": (C.c_int32, [_P, C.POINTER(C.c_uint32)]),
     "kl_set_accum_mode": (C.c_int32, [_P, C.c_uint32]),
@@ -352,6 +354,11 @@ class Renderer:
         uv = np.empty((n, 2), dtype=np.float32)
         self._ck(lib().kl_trace_rays(self._h, _ptr(o), _ptr(d), n, _ptr(t), _ptr(prim), _ptr(uv)), "kl_trace_rays")
         return t, prim, uv
+
+    def trace_rays_noalloc(self, o_dev, d_dev, n, t_dev, prim_dev, uv_dev):
+        """kl_trace_rays_noalloc: DEVICE pointers (integers) in and out, at most NOALLOC_MAX_RAYS rays, asynchronous"""
+        self._ck(lib().kl_trace_rays_noalloc(self._h, C.c_void_p(o_dev), C.c_void_p(d_dev), n, C.c_void_p(t_dev),
+                                             C.c_void_p(prim_dev), C.c_void_p(uv_dev)), "kl_trace_rays_noalloc")
 
     # -- partitioning
     def set_shard(self, rank, world, band_rows):
