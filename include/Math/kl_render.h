@@ -95,8 +95,9 @@ typedef struct kl_params {
     uint32_t frames_in_flight; /* frames traced together as one wavefront batch (0 = choose: as many as a quarter of the free memory holds, up to 64,
                                   with several lanes up to 48 and the call's frames shared equally among the lanes) */
     uint32_t fused_compaction; /* 1: shade pushes survivors itself; 0: separate compact kernel */
-    uint32_t collect_stats;    /* 1: traversal kernels count nodes/primitives/active lanes (slower) */
-    uint32_t profile_kernels;  /* 1: HIP events around every intersect launch, see kl_get_timing */
+    uint32_t collect_stats;    /* 1: an instrumented traversal kernel counts nodes / primitive tests / active lanes per lane (slower);
+                                  2: the kernel the scene runs anyway tallies the same per wave (ballot + popcount: about 1 % slower) */
+    uint32_t profile_kernels;  /* 1: HIP events around every generate / intersect / shade / accumulate launch, see kl_get_timing */
     uint32_t batch_lanes;      /* batches traced concurrently on separate HIP streams, each with its own queues: 0 = choose
                                   (two), 1 = one stream, at most 4. The image does not depend on it (batches accumulate in frame order). */
     uint32_t trace_primary_per_frame; /* 0: the camera ray of a pixel, which is the same in every frame (RawFrame.glsl:436 adds no
@@ -117,10 +118,17 @@ typedef struct kl_counters {
 } kl_counters;
 
 typedef struct kl_timing {
-    double intersect_ms;       /* sum of HIP-event durations of intersect launches (profile_kernels only) */
+    double intersect_ms;       /* sum of HIP-event durations of intersect launches (profile_kernels only; with several batch lanes
+                                  launches of different lanes overlap, so sums over kinds can exceed the wall time) */
     uint64_t intersect_launches;
     double render_ms;          /* sum of HIP-event durations of whole kl_render_frames calls */
     uint64_t render_calls;
+    double shade_ms;           /* the same per shade / generate / accumulate launch (profile_kernels only) */
+    uint64_t shade_launches;
+    double generate_ms;
+    uint64_t generate_launches;
+    double accumulate_ms;
+    uint64_t accumulate_launches;
 } kl_timing;
 
 typedef struct kl_bvh_stats {

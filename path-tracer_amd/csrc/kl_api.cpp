@@ -33,7 +33,8 @@ constexpr uint32_t KL_BRUTE_AUTO_LIMIT = 64;      // KL_ACCEL_AUTO uses the flat
 constexpr size_t KL_MAX_PENDING_EVENTS = 8192;
 constexpr uint32_t KL_QUEUE_SEGMENTS = 64;        // independent sub-queues, each with its own tail/head counter
 
-struct EventPair { hipEvent_t a, b; int kind; };   // kind 0 = intersect launch, 1 = whole render call
+enum { EV_INTERSECT = 0, EV_RENDER = 1, EV_SHADE = 2, EV_GENERATE = 3, EV_ACCUMULATE = 4 };
+struct EventPair { hipEvent_t a, b; int kind; };   // kind: which launch (or whole render call) the pair brackets
 
 template <typename T> struct DevBuf {
     T *p = nullptr; size_t n = 0;
@@ -246,8 +247,13 @@ void drain_events(kl_ctx *c) {
     for (const EventPair &p : c->pending) {
         float ms = 0.0f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            if (p.kind == 0) { c->timing.intersect_ms += ms; c->timing.intersect_launches++; }
-            else { c->timing.render_ms += ms; c->timing.render_calls++; }
+            switch (p.kind) {
+                case EV_INTERSECT: c->timing.intersect_ms += ms; c->timing.intersect_launches++; break;
+                case EV_RENDER: c->timing.render_ms += ms; c->timing.render_calls++; break;
+                case EV_SHADE: c->timing.shade_ms += ms; c->timing.shade_launches++; break;
+                case EV_GENERATE: c->timing.generate_ms += ms; c->timing.generate_launches++; break;
+                default: c->timing.accumulate_ms += ms; c->timing.accumulate_launches++; break;
+            }
         }
         c->free_events.push_back(p.a); c->free_events.push_back(p.b);
     }
@@ -293,18 +299,30 @@ kl_status timed_intersect(kl_ctx *c, BatchLane &L, const FrameDev &f, RayQueue q
     hipEvent_t a = nullptr, b = nullptr;
     const bool bvh = use_bvh(c);
     if (bvh && scene_has_flat(c->sc) && !flat_done)
-        launch_intersect_flat(L.stream, c->lc, c->sc, f, q, count, c->d_counters.p, c->params.collect_stats != 0, max_rays);
-    // the events bracket the dominant kernel only (k_intersect_bvh, or the flat loop for small scenes)
+        launch_intersect_flat(L.stream, c->lc, c->sc, f, q, count, c->d_counters.p, c->params.collect_stats == 1, max_rays);
+    // the events bracket the traversal kernel only (k_intersect_bvh, or the flat loop for small scenes)
     if (c->params.profile_kernels) {
         if (c->pending.size() >= KL_MAX_PENDING_EVENTS) drain_events(c);
         a = get_event(c); b = get_event(c);
         if (a && b) KL_HIP(c, hipEventRecord(a, L.stream));
     }
     launch_intersect(L.stream, c->lc, c->sc, f, q, count, head, c->d_counters.p, L.d_overflow.p, bvh,
-                     c->params.collect_stats != 0, max_rays, flat_done);
-    if (a && b) { KL_HIP(c, hipEventRecord(b, L.stream)); c->pending.push_back({a, b, 0}); }
+                     (int)std::min(c->params.collect_stats, 2u), max_rays, flat_done);
+    if (a && b) { KL_HIP(c, hipEventRecord(b, L.stream)); c->pending.push_back({a, b, EV_INTERSECT}); }
     return KL_OK;
 }
+
+// profile_kernels: HIP events around one launch of the given kind on the lane's stream (begin before, end after)
+struct Bracket {
+    kl_ctx *c; hipStream_t s; int kind; hipEvent_t a = nullptr, b = nullptr;
+    Bracket(kl_ctx *ctx, hipStream_t stream, int k) : c(ctx), s(stream), kind(k) {
+        if (!c->params.profile_kernels) return;
+        if (c->pending.size() >= KL_MAX_PENDING_EVENTS) drain_events(c);
+        a = get_event(c); b = get_event(c);
+        if (a && b) (void)hipEventRecord(a, s);
+    }
+    ~Bracket() { if (a && b && hipEventRecord(b, s) == hipSuccess) c->pending.push_back({a, b, kind}); }
+};
 
 // one wavefront batch on lane L: frames [first, first+nslots) traced together, then accumulated in order.
 // `after` (may be null): the accumulate of the batch before this one, which this batch's accumulate follows.
@@ -333,11 +351,12 @@ kl_status render_batch(kl_ctx *c, BatchLane &L, hipEvent_t after, uint32_t first
         KL_HIP(c, hipMemsetAsync(count1, 0, S * sizeof(uint32_t), L.stream));
         KL_HIP(c, hipMemsetAsync(head1, 0, S * sizeof(uint32_t), L.stream));
         RayQueue q1 = { L.p_od.p, L.p_dt.p, nullptr, L.p_uv.p };
-        launch_generate(L.stream, c->lc, c->sc, f1, q1, count1, pflat);
+        { Bracket t(c, L.stream, EV_GENERATE); launch_generate(L.stream, c->lc, c->sc, f1, q1, count1, pflat); }
         kl_status s1 = timed_intersect(c, L, f1, q1, count1, head1, c->npl, pflat);
         if (s1 != KL_OK) return s1;
-        launch_generate(L.stream, c->lc, c->sc, f, q[0], count, false, q1, c->segcap1);
+        { Bracket t(c, L.stream, EV_GENERATE); launch_generate(L.stream, c->lc, c->sc, f, q[0], count, false, q1, c->segcap1); }
     } else {
+        Bracket t(c, L.stream, EV_GENERATE);
         launch_generate(L.stream, c->lc, c->sc, f, q[0], count, pflat);
     }
     for (uint32_t b = 0; b < levels; b++) {
@@ -346,12 +365,15 @@ kl_status render_batch(kl_ctx *c, BatchLane &L, hipEvent_t after, uint32_t first
             kl_status s = timed_intersect(c, L, f, qi, count + (size_t)b * S, head + (size_t)b * S, max_rays, pflat);
             if (s != KL_OK) return s;
         }
-        launch_shade(L.stream, c->lc, c->sc, f, qi, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, L.d_raw.p, b, fused, max_rays,
-                     pflat && b + 1 < levels);
+        {
+            Bracket t(c, L.stream, EV_SHADE);
+            launch_shade(L.stream, c->lc, c->sc, f, qi, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, L.d_raw.p, b, fused, max_rays,
+                         pflat && b + 1 < levels);
+        }
         if (!fused && b + 1 < levels) launch_compact(L.stream, c->lc, f, qi, count + (size_t)b * S, qo, count + (size_t)(b + 1) * S, max_rays);
     }
     if (after) KL_HIP(c, hipStreamWaitEvent(L.stream, after, 0));
-    launch_accumulate(L.stream, c->lc, f, L.d_raw.p, c->d_acc.p, c->d_last_raw.p, camera_change, c->accum_mode);
+    { Bracket t(c, L.stream, EV_ACCUMULATE); launch_accumulate(L.stream, c->lc, f, L.d_raw.p, c->d_acc.p, c->d_last_raw.p, camera_change, c->accum_mode); }
     KL_HIP(c, hipGetLastError());
     return KL_OK;
 }
@@ -398,7 +420,7 @@ void flat_quad_terms(const kl_quad &x, float4 *f) {
 
 extern "C" {
 
-uint32_t kl_abi_version(void) { return 1; }
+uint32_t kl_abi_version(void) { return 2; }
 
 const char *kl_status_string(kl_status s) {
     switch (s) {
@@ -846,7 +868,7 @@ static kl_status kl_render_frames_body(kl_ctx *c, uint32_t n, uint32_t first_fra
     for (uint32_t l = 1; l < lanes; l++)
         if (lane_used[l]) KL_HIP(c, hipStreamWaitEvent(c->stream, c->lanes[l].done, 0));
     c->frame = frame;                   // iFrame++ per frame, GLSL_Renderer.cpp:347
-    if (ea && eb) { KL_HIP(c, hipEventRecord(eb, c->stream)); c->pending.push_back({ea, eb, 1}); }
+    if (ea && eb) { KL_HIP(c, hipEventRecord(eb, c->stream)); c->pending.push_back({ea, eb, EV_RENDER}); }
     return KL_OK;
 }
 kl_status kl_render_frames(kl_ctx *c, uint32_t n, uint32_t first_frame) {
@@ -953,9 +975,9 @@ static kl_status kl_trace_rays_body(kl_ctx *c, const float *o, const float *d, u
     f.all_uv = 1;                                   // (u, v) of every hit, whatever its material
     RayQueue q = { b_od.p, b_dt.p, nullptr, b_quv.p };
     if (use_bvh(c) && scene_has_flat(c->sc))
-        launch_intersect_flat(c->stream, c->lc, c->sc, f, q, &b_ctl.p[0], c->d_counters.p, c->params.collect_stats != 0, n);
+        launch_intersect_flat(c->stream, c->lc, c->sc, f, q, &b_ctl.p[0], c->d_counters.p, c->params.collect_stats == 1, n);
     launch_intersect(c->stream, c->lc, c->sc, f, q, &b_ctl.p[0], &b_ctl.p[1], c->d_counters.p, c->lanes[0].d_overflow.p, use_bvh(c),
-                     c->params.collect_stats != 0, n);
+                     (int)std::min(c->params.collect_stats, 2u), n);
     launch_unpack_hits(c->stream, c->sc, q, n, b_t.p, b_prim.p, b_uv.p);
     KL_HIP(c, hipMemcpyAsync(t, b_t.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     KL_HIP(c, hipMemcpyAsync(prim, b_prim.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

@@ -390,7 +390,10 @@ __device__ __forceinline__ void coop_fetch_one(const float4 *base, uint32_t my_o
 // TYPES: which primitive types the tree holds (bit PRIM_*). The leaf branch of a kernel built for one type is that
 // type's test alone; the test code of types a scene does not have costs registers even if it never runs (all three:
 // 80 VGPRs and two spilled; triangles only: 54), and with them the scheduling freedom of the whole loop.
-template <bool STATS, uint32_t TYPES>
+// STATS: 0 = none; 1 = per-lane tallies of nodes and primitive tests (the instrumented all-types instance); 2 = wave-level
+// tallies only (ballot + popcount into scalar registers): lane-steps on nodes and on primitives and active lanes per step, cheap
+// enough that the timed instance itself reports its own lane use and steps per ray.
+template <int STATS, uint32_t TYPES>
 __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_intersect_bvh(SceneDev sc, FrameDev f, RayQueue q, uint32_t tally_flat,
                                                                    const uint32_t *counts, uint32_t *heads, Counters *cn, int *overflow) {
     __shared__ int stack[ISECT_WAVES][ISECT_LDS_STACK][64];
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
     const uint32_t seg_base = seg * f.segcap;
     if (blockIdx.x < f.nseg && threadIdx.x == 0 && count) {
         atomicAdd(&cn->rays, (unsigned long long)count);
-        if (STATS && tally_flat) {            // flat tests done by the kernel that produced the rays: tallied here
+        if (STATS == 1 && tally_flat) {            // flat tests done by the kernel that produced the rays: tallied here
             atomicAdd(&cn->sphere_tests, (unsigned long long)count * sc.flat_count[PRIM_SPHERE]);
             atomicAdd(&cn->quad_tests, (unsigned long long)count * sc.flat_count[PRIM_QUAD]);
             atomicAdd(&cn->tri_tests, (unsigned long long)count * sc.flat_count[PRIM_TRI]);
@@ -497,6 +500,16 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
             const uint32_t tp = sp > 0 ? (uint32_t)(sp - 1) : 0u;
             int top = st[min(tp, ISECT_LDS_STACK - 1u) * 64u];
             if (active && tp >= ISECT_LDS_STACK) top = ovf[(tp - ISECT_LDS_STACK) * 64u];
+            if (STATS == 2) {      // wave-level tallies: one ballot per class, counts stay in scalar registers
+                constexpr uint32_t T = 1u << PRIM_TRI, S = 1u << PRIM_SPHERE, Q = 1u << PRIM_QUAD;
+                s_nodes += (unsigned long long)__popcll(__ballot(active && inner));
+                if (TYPES == T) s_tri += (unsigned long long)__popcll(__ballot(active && !inner));
+                else {
+                    if (TYPES & T) s_tri += (unsigned long long)__popcll(__ballot(active && !inner && type == PRIM_TRI));
+                    if (TYPES & S) s_sph += (unsigned long long)__popcll(__ballot(active && !inner && type == PRIM_SPHERE));
+                    if (TYPES & Q) s_quad += (unsigned long long)__popcll(__ballot(active && !inner && type == PRIM_QUAD));
+                }
+            }
             const float4 *mine = &stage[wave_in_block][lane & 3u][(lane >> 2) * 4u];
             const float4 n0 = mine[0], n1 = mine[1], n2 = mine[2], n3 = mine[3];
             if (active) {
@@ -507,7 +520,7 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                     sp++;
                 };
                 if (inner) {
-                    if (STATS) s_nodes++;
+                    if (STATS == 1) s_nodes++;
                     // four child boxes on the node's 8-bit grid: plane = lo + byte * step, so along the ray
                     // t = byte * (step * 1/d) + (lo - o) * 1/d; near and far planes are picked by the sign of 1/d.
                     // An empty slot holds an inverted box and fails the test by itself.
@@ -555,9 +568,9 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
                     } else pop = true;
                 } else {
                     constexpr uint32_t T = 1u << PRIM_TRI, S = 1u << PRIM_SPHERE, Q = 1u << PRIM_QUAD;
-                    if (TYPES == T || ((TYPES & T) && type == PRIM_TRI)) { test_tri(n0, n1, n2, start, o, d, h, &sc); if (STATS) s_tri++; }
-                    else if (TYPES == S || ((TYPES & S) && type == PRIM_SPHERE)) { test_sphere(n0, n1, start, o, d, f.eps, h, &sc); if (STATS) s_sph++; }
-                    else if (TYPES & Q) { test_quad(n0, n1, n2, n3, start, o, d, h, &sc); if (STATS) s_quad++; }
+                    if (TYPES == T || ((TYPES & T) && type == PRIM_TRI)) { test_tri(n0, n1, n2, start, o, d, h, &sc); if (STATS == 1) s_tri++; }
+                    else if (TYPES == S || ((TYPES & S) && type == PRIM_SPHERE)) { test_sphere(n0, n1, start, o, d, f.eps, h, &sc); if (STATS == 1) s_sph++; }
+                    else if (TYPES & Q) { test_quad(n0, n1, n2, n3, start, o, d, h, &sc); if (STATS == 1) s_quad++; }
                     if ((lv >> 26) & 7u) node = ~(int)(lv + 1u - (1u << 26));   // next primitive of this leaf
                     else pop = true;
                 }
@@ -584,11 +597,12 @@ __global__ __launch_bounds__(64 * ISECT_WAVES, KL_ISECT_MIN_WAVES) void k_inters
         } while ((uint32_t)__popcll(am) >= thresh);
     }
     if (STATS) {
-        // lane sums -> one atomic per wave per counter
-        for (int off = 32; off > 0; off >>= 1) {
-            s_nodes += __shfl_down(s_nodes, off); s_sph += __shfl_down(s_sph, off);
-            s_quad += __shfl_down(s_quad, off); s_tri += __shfl_down(s_tri, off);
-        }
+        // lane sums -> one atomic per wave per counter (the wave-level tallies are already whole-wave sums)
+        if (STATS == 1)
+            for (int off = 32; off > 0; off >>= 1) {
+                s_nodes += __shfl_down(s_nodes, off); s_sph += __shfl_down(s_sph, off);
+                s_quad += __shfl_down(s_quad, off); s_tri += __shfl_down(s_tri, off);
+            }
         if (lane == 0) {
             atomicAdd(&cn->nodes, s_nodes); atomicAdd(&cn->sphere_tests, s_sph);
             atomicAdd(&cn->quad_tests, s_quad); atomicAdd(&cn->tri_tests, s_tri);
@@ -958,7 +972,7 @@ void launch_intersect_flat(hipStream_t s, const LaunchCfg &lc, const SceneDev &s
     hipLaunchKernelGGL(k_intersect_flat, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, counts, cn, stats ? 1u : 0u);
 }
 void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q,
-                      const uint32_t *counts, uint32_t *heads, Counters *cn, int *overflow, bool bvh, bool stats, uint32_t max_rays,
+                      const uint32_t *counts, uint32_t *heads, Counters *cn, int *overflow, bool bvh, int stats, uint32_t max_rays,
                       bool flat_by_producer) {
     if (!bvh) {
         hipLaunchKernelGGL(k_intersect_brute, dim3(seg_grid(f, max_rays, lc.cus * 8u, 256u)), dim3(256), 0, s, sc, f, q, counts, cn);
@@ -970,16 +984,13 @@ void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, co
     uint32_t types = 0u;
     for (uint32_t t = 0; t < 3u; t++) types |= sc.count[t] > sc.flat_count[t] ? 1u << t : 0u;
 #define KL_ISECT_LAUNCH(ST, TY) hipLaunchKernelGGL((k_intersect_bvh<ST, TY>), dim3(blocks), dim3(64 * ISECT_WAVES), 0, s, sc, f, q, tally_flat, counts, heads, cn, overflow)
-    if (stats) { KL_ISECT_LAUNCH(true, 7u); return; }
-    switch (types) {
-        case 1u: KL_ISECT_LAUNCH(false, 1u); break;
-        case 2u: KL_ISECT_LAUNCH(false, 2u); break;
-        case 3u: KL_ISECT_LAUNCH(false, 3u); break;
-        case 4u: KL_ISECT_LAUNCH(false, 4u); break;
-        case 5u: KL_ISECT_LAUNCH(false, 5u); break;
-        case 6u: KL_ISECT_LAUNCH(false, 6u); break;
-        default: KL_ISECT_LAUNCH(false, 7u); break;
-    }
+    if (stats == 1) { KL_ISECT_LAUNCH(1, 7u); return; }
+#define KL_ISECT_BY_TYPES(ST) switch (types) { \
+        case 1u: KL_ISECT_LAUNCH(ST, 1u); break; case 2u: KL_ISECT_LAUNCH(ST, 2u); break; case 3u: KL_ISECT_LAUNCH(ST, 3u); break; \
+        case 4u: KL_ISECT_LAUNCH(ST, 4u); break; case 5u: KL_ISECT_LAUNCH(ST, 5u); break; case 6u: KL_ISECT_LAUNCH(ST, 6u); break; \
+        default: KL_ISECT_LAUNCH(ST, 7u); break; }
+    if (stats == 2) { KL_ISECT_BY_TYPES(2) } else { KL_ISECT_BY_TYPES(0) }
+#undef KL_ISECT_BY_TYPES
 #undef KL_ISECT_LAUNCH
 }
 void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin,
@@ -1068,7 +1079,7 @@ hipError_t launch_trace_noalloc(hipStream_t s, int device, const LaunchCfg &lc, 
     if (bvh && scene_has_flat(sc)) launch_intersect_flat(s, lc, sc, f, q, ctl, cn, false, n);
     LaunchCfg small = lc;                       // the overflow slab in `scratch` is sized for NOALLOC_BLOCKS workgroups
     small.cus = NOALLOC_BLOCKS; small.isect_blocks_per_cu = 1;
-    launch_intersect(s, small, sc, f, q, ctl, ctl + CTR_STRIDE, cn, ovf, bvh, false, n);
+    launch_intersect(s, small, sc, f, q, ctl, ctl + CTR_STRIDE, cn, ovf, bvh, 0, n);
     launch_unpack_hits(s, sc, q, n, t, prim, uv);
     return hipGetLastError();
 }

@@ -23,9 +23,10 @@ bool scene_has_flat(const SceneDev &sc);
 // the flat primitives for every ray of a queue; the render loop runs them inside generate / shade instead
 void launch_intersect_flat(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q,
                            const uint32_t *counts, Counters *cn, bool stats, uint32_t max_rays);
-// closest hits into the queue entries (and q.uv); flat_by_producer only says who tallies the flat tests in statistics
+// closest hits into the queue entries (and q.uv); stats: 0 none, 1 the instrumented all-types kernel, 2 wave-level tallies in the
+// kernel the scene would run anyway; flat_by_producer only says who tallies the flat tests in statistics
 void launch_intersect(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue q,
-                      const uint32_t *count, uint32_t *head, Counters *cn, int *overflow, bool bvh, bool stats, uint32_t max_rays,
+                      const uint32_t *count, uint32_t *head, Counters *cn, int *overflow, bool bvh, int stats, uint32_t max_rays,
                       bool flat_by_producer = false);
 // flat (with fused compaction): the pushed rays leave with their flat-primitive hit; otherwise with a miss
 void launch_shade(hipStream_t s, const LaunchCfg &lc, const SceneDev &sc, const FrameDev &f, RayQueue qin,

@@ -54,7 +54,10 @@ class Counters(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("intersect_ms", C.c_double), ("intersect_launches", C.c_uint64),
-                ("render_ms", C.c_double), ("render_calls", C.c_uint64)]
+                ("render_ms", C.c_double), ("render_calls", C.c_uint64),
+                ("shade_ms", C.c_double), ("shade_launches", C.c_uint64),
+                ("generate_ms", C.c_double), ("generate_launches", C.c_uint64),
+                ("accumulate_ms", C.c_double), ("accumulate_launches", C.c_uint64)]
 
 
 class BvhStats(C.Structure):
@@ -198,6 +201,7 @@ class Renderer:
         if rc != 0:
             raise KlError("kl_create failed: %s" % lib().kl_status_string(rc).decode())
         self.width, self.height, self.device = width, height, device
+        self.shard = (0, 1, 1)
 
     # -- plumbing
     def _ck(self, rc, what):
@@ -363,6 +367,7 @@ class Renderer:
     # -- partitioning
     def set_shard(self, rank, world, band_rows):
         self._ck(lib().kl_set_shard(self._h, rank, world, band_rows), "kl_set_shard")
+        self.shard = (rank, world, band_rows)
 
     def set_accum_mode(self, mode):
         self._ck(lib().kl_set_accum_mode(self._h, mode), "kl_set_accum_mode")

@@ -13,23 +13,40 @@ import torch.distributed as dist
 from . import partition
 
 
+class TileGather:
+    """Buffers and index of the image-tile exchange for one (height, width, world, band_rows), allocated once: the padded
+    send block, the all-gathered blocks and the row index that un-tiles them with ONE gather (no per-rank Python loop)."""
+
+    def __init__(self, height, width, band_rows, device, group=None, channels=4, dtype=torch.float32):
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.height, self.width, self.band_rows = height, width, band_rows
+        self.pad_rows = partition.max_local_rows(height, self.world, band_rows)
+        self.rows = len(partition.rows_of_rank(height, self.rank, self.world, band_rows))
+        self.gathered = torch.empty((self.world * self.pad_rows, width, channels), dtype=dtype, device=device)
+        # this rank's block of the gathered buffer doubles as its send buffer (in-place all_gather: no staging copy)
+        self.send = self.gathered[self.rank * self.pad_rows:(self.rank + 1) * self.pad_rows]
+        if self.rows < self.pad_rows:
+            self.send[self.rows:].zero_()
+        self.index = torch.as_tensor(partition.untile_index(height, self.world, band_rows), device=device, dtype=torch.long)
+        self.full = torch.empty((height, width, channels), dtype=dtype, device=device)
+
+    def local_view(self):
+        """(local_rows, W, C) view of the send block: where this rank's rows go before gather()"""
+        return self.send[:self.rows]
+
+    def gather(self):
+        dist.all_gather_into_tensor(self.gathered, self.send, group=self.group)
+        torch.index_select(self.gathered, 0, self.index, out=self.full)
+        return self.full
+
+
 def gather_tiles(local, height, band_rows, group=None):
-    """local: (local_rows, W, 4) float32 tensor of this rank's row bands. Returns the full
-    (H, W, 4) image on every rank. Ranks may own different row counts (ragged last band):
-    buffers are padded to the largest count for the all_gather."""
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    width, ch = local.shape[1], local.shape[2]
-    pad_rows = partition.max_local_rows(height, world, band_rows)
-    buf = torch.zeros((pad_rows, width, ch), dtype=local.dtype, device=local.device)
-    buf[:local.shape[0]] = local
-    parts = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(parts, buf, group=group)
-    out = torch.empty((height, width, ch), dtype=local.dtype, device=local.device)
-    for r in range(world):
-        rows = torch.as_tensor(partition.rows_of_rank(height, r, world, band_rows), device=local.device)
-        if len(rows):
-            out[rows] = parts[r][:len(rows)]
-    return out
+    """local: (local_rows, W, 4) float32 tensor of this rank's row bands. Returns the full (H, W, 4) image on every
+    rank. Ranks may own different row counts (ragged last band): blocks are padded to the largest count."""
+    tg = TileGather(height, local.shape[1], band_rows, local.device, group, channels=local.shape[2], dtype=local.dtype)
+    tg.local_view().copy_(local)
+    return tg.gather()
 
 
 def reduce_samples(local_sum, n_frames_total, group=None):
@@ -45,17 +62,23 @@ def _device_of(renderer):
     return torch.device("cuda", renderer.device)
 
 
-def render_tiles(renderer, n_frames, band_rows, first_frame=0, group=None):
-    """Image-tile partition on the HIP path: shards `renderer` by row bands, renders, gathers."""
+def render_tiles(renderer, n_frames, band_rows, first_frame=0, group=None, gatherer=None):
+    """Image-tile partition on the HIP path: shards `renderer` by row bands, renders, gathers. `gatherer`: a TileGather
+    to reuse between calls (its buffers are then not reallocated)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    renderer.set_shard(rank, world, band_rows)
+    if renderer.shard != (rank, world, band_rows):
+        renderer.set_shard(rank, world, band_rows)
+    else:
+        renderer.reset()
     renderer.render_frames(n_frames, first_frame=first_frame)
-    rows = renderer.local_rows
-    local = torch.empty((rows, renderer.width, 4), dtype=torch.float32, device=_device_of(renderer))
-    if rows:
-        # the copy runs on the renderer's own stream and returns when it has landed; nothing of torch's is pending on `local`
-        renderer.copy_accum_to_device(local.data_ptr(), local.numel() * 4)
-    return gather_tiles(local, renderer.height, band_rows, group)
+    tg = gatherer or TileGather(renderer.height, renderer.width, band_rows, _device_of(renderer), group)
+    assert tg.rows == renderer.local_rows
+    # torch's stream may still read the block (previous gather): wait, then let the renderer's stream copy into it
+    torch.cuda.current_stream(tg.gathered.device).synchronize()
+    if tg.rows:
+        view = tg.local_view()
+        renderer.copy_accum_to_device(view.data_ptr(), view.numel() * 4)
+    return tg.gather()
 
 
 def live_frames(first_frame, n_frames, max_frames):

@@ -34,3 +34,13 @@ def frame_range(first, n, rank, world):
     lo = first + (n * rank) // world
     hi = first + (n * (rank + 1)) // world
     return lo, hi
+
+
+def untile_index(height, world, band_rows):
+    """For the all-gathered buffer of `world` padded per-rank blocks (each max_local_rows rows): the row of that buffer
+    which holds image row y, for every y. One index gather with it un-tiles the image (what a HIP un-tile kernel computes
+    per pixel: rank = (y // band_rows) % world, local row = (y // band_rows // world) * band_rows + y % band_rows)."""
+    pad = max_local_rows(height, world, band_rows)
+    y = np.arange(height)
+    band = y // band_rows
+    return (band % world) * pad + (band // world) * band_rows + y % band_rows

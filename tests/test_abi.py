@@ -26,7 +26,7 @@ def test_header_symbols_exported():
         assert hasattr(L, n), "libklrender.so does not export %s" % n
         assert n in kl.SIGNATURES, "python binding lacks %s" % n
     assert set(kl.SIGNATURES) == set(names)
-    assert L.kl_abi_version() == 1
+    assert L.kl_abi_version() == 2
 
 
 def test_forwarding_header():
