@@ -105,7 +105,10 @@ typedef struct kl_params {
                                   1: traced again for every frame, as the shader does. The image is the same either way. */
     uint32_t bvh_builder;      /* KL_BUILD_*, read by the next kl_upload_scene / kl_load_mesh; a GPU build whose tree turns out
                                   deeper than the traversal stack allows is redone on the host (kl_bvh_stats.builder says which ran) */
-    uint32_t reserved[2];
+    uint32_t spp_grid;         /* SPP, 1: spp_grid x spp_grid sub-samples per pixel and frame in the AO and path-traced modes, each offset
+                                  by (x / SPP, y / SPP) of a pixel and all sharing the frame's random numbers (RawFrame.glsl:37,434-440,
+                                  446-453); the raw frame is their sum divided by SPP * SPP. 0 = 1; at most 8 */
+    uint32_t reserved[1];
 } kl_params;
 
 typedef struct kl_counters {

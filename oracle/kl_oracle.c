@@ -192,7 +192,7 @@ void ko_default_params(ko_params *p) {
     p->width = 1920; p->height = 1080; p->mode = KO_MODE_PT;
     p->max_bounces = 32; p->max_frames = 30;
     p->eps = 0.001f; p->max_dist = 5000.0f; p->ao_length = 1.0f; p->hdri_strength = 1.0f;
-    p->use_bvh = 0;
+    p->use_bvh = 0; p->spp = 1;
 }
 void ko_default_camera(ko_camera *c) {
     c->pos[0] = 0; c->pos[1] = 1; c->pos[2] = 5;
@@ -679,15 +679,17 @@ static v3 radiance(const ko_scene *s, const ko_params *p, v3 o, v3 d, const floa
 }
 
 /* RF:417-422 and the uv arithmetic of RF:428-429,436 */
-void ko_camera_ray(const ko_camera *c, uint32_t w, uint32_t h, uint32_t x, uint32_t y, int subpixel, float o[3], float d[3]) {
+/* sub-sample (sx, sy) of the SPP x SPP grid of RF:434-436,446-448 */
+static void camera_ray_sub(const ko_camera *c, uint32_t w, uint32_t h, uint32_t x, uint32_t y, int subpixel, uint32_t sx, uint32_t sy,
+                           uint32_t spp, float o[3], float d[3]) {
     float rx = (float)w, ry = (float)h;
     float m = fmaxf(rx, ry);
     float ux = (((float)x + 0.5f) - 1.0f - rx / 2.0f) / m;
     float uy = (((float)y + 0.5f) - 1.0f - ry / 2.0f) / m;
-    if (subpixel) {                                   /* RF:436 with SPP = 1, x = y = 0 */
+    if (subpixel) {                                   /* RF:436: uv - 0.5 * pixel_size + vec2(x / SPP, y / SPP) * pixel_size */
         float psx = 1.0f / rx, psy = 1.0f / ry;
-        ux = (ux - 0.5f * psx) + (0.0f / 1.0f) * psx;
-        uy = (uy - 0.5f * psy) + (0.0f / 1.0f) * psy;
+        ux = (ux - 0.5f * psx) + ((float)sx / (float)spp) * psx;
+        uy = (uy - 0.5f * psy) + ((float)sy / (float)spp) * psy;
     }
     v3 pos = V(c->pos[0], c->pos[1], c->pos[2]), front = V(c->front[0], c->front[1], c->front[2]);
     v3 up = V(c->up[0], c->up[1], c->up[2]);
@@ -697,6 +699,9 @@ void ko_camera_ray(const ko_camera *c, uint32_t w, uint32_t h, uint32_t x, uint3
     v3 dir = vnormalize(vsub(vadd(vadd(pc, vscale(pu, ux)), vscale(pv, uy)), pos));
     o[0] = pos.x; o[1] = pos.y; o[2] = pos.z;
     d[0] = dir.x; d[1] = dir.y; d[2] = dir.z;
+}
+void ko_camera_ray(const ko_camera *c, uint32_t w, uint32_t h, uint32_t x, uint32_t y, int subpixel, float o[3], float d[3]) {
+    camera_ray_sub(c, w, h, x, y, subpixel, 0, 0, 1, o, d);      /* SPP = 1 as shipped */
 }
 
 /* RF:425-464 for rows [y0,y1) */
@@ -726,14 +731,22 @@ int ko_render_raw(const ko_scene *s, const ko_camera *cam, const ko_params *p, u
                 ko_rand4(x, y, frame, r);
                 v3 col = V(0, 0, 0);
                 cn.paths++;
-                if (p->mode == KO_MODE_AO) {
-                    ko_camera_ray(cam, p->width, p->height, x, y, 1, o, d);
-                    col = vadd(col, ambient_occlusion(s, p, V(o[0], o[1], o[2]), V(d[0], d[1], d[2]), r, &cn));
-                    col = V(col.x / 1.0f, col.y / 1.0f, col.z / 1.0f);
-                } else if (p->mode == KO_MODE_PT) {
-                    ko_camera_ray(cam, p->width, p->height, x, y, 1, o, d);
-                    col = vadd(col, radiance(s, p, V(o[0], o[1], o[2]), V(d[0], d[1], d[2]), r, &cn));
-                    col = V(col.x / 1.0f, col.y / 1.0f, col.z / 1.0f);
+                const uint32_t spp = p->spp ? p->spp : 1u;            /* #define SPP, RF:37 */
+                const float nsub = (float)(spp * spp);
+                if (p->mode == KO_MODE_AO) {                          /* RF:432-442; every sub-sample sees the same random numbers */
+                    for (uint32_t sx = 0; sx < spp; sx++)
+                        for (uint32_t sy = 0; sy < spp; sy++) {
+                            camera_ray_sub(cam, p->width, p->height, x, y, 1, sx, sy, spp, o, d);
+                            col = vadd(col, ambient_occlusion(s, p, V(o[0], o[1], o[2]), V(d[0], d[1], d[2]), r, &cn));
+                        }
+                    col = V(col.x / nsub, col.y / nsub, col.z / nsub);
+                } else if (p->mode == KO_MODE_PT) {                   /* RF:444-455 */
+                    for (uint32_t sx = 0; sx < spp; sx++)
+                        for (uint32_t sy = 0; sy < spp; sy++) {
+                            camera_ray_sub(cam, p->width, p->height, x, y, 1, sx, sy, spp, o, d);
+                            col = vadd(col, radiance(s, p, V(o[0], o[1], o[2]), V(d[0], d[1], d[2]), r, &cn));
+                        }
+                    col = V(col.x / nsub, col.y / nsub, col.z / nsub);
                 } else {
                     ko_camera_ray(cam, p->width, p->height, x, y, 0, o, d);
                     col = zdepth(s, p, V(o[0], o[1], o[2]), V(d[0], d[1], d[2]), &cn);

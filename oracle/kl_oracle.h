@@ -43,6 +43,7 @@ typedef struct {
     float ao_length;        /* AO_LENGTH :33 */
     float hdri_strength;    /* HDRI_STRENGTH :32 */
     int32_t use_bvh;        /* 0 = brute force in declaration order, 1 = oracle's own BVH */
+    uint32_t spp;           /* SPP, :37: spp x spp sub-samples per pixel and frame in the AO and path-traced modes; 0 = 1 */
 } ko_params;
 
 typedef struct {

@@ -33,7 +33,7 @@ class Params(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("mode", C.c_uint32),
                 ("max_bounces", C.c_uint32), ("max_frames", C.c_uint32),
                 ("eps", C.c_float), ("max_dist", C.c_float), ("ao_length", C.c_float),
-                ("hdri_strength", C.c_float), ("use_bvh", C.c_int32)]
+                ("hdri_strength", C.c_float), ("use_bvh", C.c_int32), ("spp", C.c_uint32)]
 
 
 class Counters(C.Structure):

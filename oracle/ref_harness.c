@@ -14,7 +14,7 @@
  *      source/Rendering/Opengl/FBT.cpp:6 so float values are observable;
  *   2. --zero-col turns `vec3 col;` (RawFrame.glsl:433,445) into
  *      `vec3 col = vec3(0);`;
- *   3. --bounces / --samples rewrite the RAY_BOUNCES / SAMPLES defines
+ *   3. --bounces / --samples / --spp rewrite the RAY_BOUNCES / SAMPLES / SPP defines
  *      (RawFrame.glsl:36,38);
  *   4. the accumulation pass ping-pongs between two textures instead of
  *      sampling the texture it renders to (GLSL_Renderer.cpp:312-324).
@@ -175,7 +175,7 @@ int main(int argc, char **argv) {
     const char *out_raw = NULL, *out_acc = NULL;
     const char *hdri_path = NULL, *albedo_path = NULL;
     int hdri_w = 1, hdri_h = 1, hdri_c = 4, alb_w = 1, alb_h = 1, alb_c = 4;
-    int mode = 2, first_frame = 0, nframes = 1, zero_col = 0, bounces = -1, samples = -1, timing = 0;
+    int mode = 2, first_frame = 0, nframes = 1, zero_col = 0, bounces = -1, samples = -1, spp = -1, timing = 0;
     float cam_pos[3] = {0, 1, 5}, cam_front[3] = {0, 0, -1}, cam_up[3] = {0, 1, 0};
     float focal = 0.05f, sensor = 0.036f;
 
@@ -191,6 +191,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--zero-col")) zero_col = 1;
         else if (!strcmp(a, "--bounces")) bounces = atoi(NEXT);
         else if (!strcmp(a, "--samples")) samples = atoi(NEXT);
+        else if (!strcmp(a, "--spp")) spp = atoi(NEXT);
         else if (!strcmp(a, "--timing")) timing = 1;
         else if (!strcmp(a, "--out-raw")) out_raw = NEXT;
         else if (!strcmp(a, "--out-acc")) out_acc = NEXT;
@@ -250,6 +251,10 @@ int main(int argc, char **argv) {
     if (bounces >= 0) {
         char to[64]; snprintf(to, sizeof to, "#define RAY_BOUNCES   %d", bounces);
         raw_src = replace_once(raw_src, "#define RAY_BOUNCES   32", to, 1);
+    }
+    if (spp >= 0) {
+        char to[64]; snprintf(to, sizeof to, "#define SPP           %d", spp);
+        raw_src = replace_once(raw_src, "#define SPP           1", to, 1);
     }
     if (samples >= 0) {
         char to[64]; snprintf(to, sizeof to, "#define SAMPLES       %d", samples);

@@ -146,6 +146,12 @@ void compute_local(kl_ctx *c) {
     c->npl = rows * c->width;
 }
 
+// sub-samples per pixel and frame: SPP x SPP in the AO and path-traced modes (RawFrame.glsl:434-436,446-448), one in ZDepth (:458)
+uint32_t sub_samples(const kl_ctx *c) {
+    const uint32_t s = std::max(1u, c->params.spp_grid);
+    return c->mode == KL_MODE_Z ? 1u : s * s;
+}
+
 uint32_t choose_slots(kl_ctx *c) {
     uint32_t f = c->params.frames_in_flight;
     if (f == 0 && c->auto_slots && c->auto_slots_npl == c->npl) return c->auto_slots;    // decided once per image size
@@ -166,6 +172,8 @@ uint32_t choose_slots(kl_ctx *c) {
         while (f > 1 && (uint64_t)f * npl >= (1ull << 31)) f--;
         c->auto_slots = f; c->auto_slots_npl = c->npl;
     }
+    // a caller's frames_in_flight counts frames: sub_samples() slots each
+    if (c->params.frames_in_flight != 0) f = f * sub_samples(c);
     return std::max(1u, std::min(f, KL_MAX_FRAMES_IN_FLIGHT));
 }
 
@@ -181,7 +189,7 @@ uint32_t choose_lanes(kl_ctx *c) {
 // with automatic sizing and several lanes at most 48 (beyond that two concurrent batches were measured slower than
 // one) and an equal share for every lane, so that no lane idles at the end
 uint32_t frames_per_batch(kl_ctx *c, uint32_t n, uint32_t lanes) {
-    uint32_t cap = choose_slots(c);
+    uint32_t cap = std::max(1u, choose_slots(c) / sub_samples(c));      // a frame takes one slot per sub-sample
     if (c->params.frames_in_flight != 0 || lanes < 2 || n < 2) return std::max(1u, std::min(cap, n));
     cap = std::min(cap, 48u);
     uint32_t nb = (n + cap - 1) / cap;
@@ -194,15 +202,16 @@ uint32_t frames_per_batch(kl_ctx *c, uint32_t n, uint32_t lanes) {
 // and does not allocate for 64 frames either.
 kl_status ensure_buffers(kl_ctx *c, uint32_t lanes = 1, uint32_t frames = 1) {
     KL_HIP(c, hipSetDevice(c->device));
-    uint32_t slots = std::max(1u, std::min(choose_slots(c), frames));
-    if (c->slots_npl == c->npl && c->slots > slots && c->slots <= choose_slots(c)) slots = c->slots;
+    const uint32_t s2 = sub_samples(c);
+    uint32_t slots = std::max(s2, std::min(choose_slots(c) / s2 * s2, frames * s2));      // whole frames: s2 slots each
+    if (c->slots_npl == c->npl && c->slots > slots && c->slots <= std::max(s2, choose_slots(c))) slots = c->slots;
     const size_t cap = (size_t)slots * c->npl;
     if (cap >= (1ull << 31)) return fail(c, KL_E_LIMIT, "frames_in_flight x pixels exceeds 2^31 paths");
     c->slots = slots; c->slots_npl = c->npl;
     const size_t groups = (cap + 63) / 64;
     c->segcap = (uint32_t)((groups + KL_QUEUE_SEGMENTS - 1) / KL_QUEUE_SEGMENTS * 64);
     const size_t qcap = (size_t)c->segcap * KL_QUEUE_SEGMENTS;
-    c->segcap1 = (uint32_t)((((size_t)c->npl + 63) / 64 + KL_QUEUE_SEGMENTS - 1) / KL_QUEUE_SEGMENTS * 64);
+    c->segcap1 = (uint32_t)((((size_t)c->npl * s2 + 63) / 64 + KL_QUEUE_SEGMENTS - 1) / KL_QUEUE_SEGMENTS * 64);   // one frame's camera rays
     const size_t qcap1 = std::max<size_t>((size_t)c->segcap1 * KL_QUEUE_SEGMENTS, 1);
     lanes = std::max(1u, std::min(lanes, KL_MAX_BATCH_LANES));
     for (uint32_t l = 0; l < lanes; l++) {
@@ -262,7 +271,8 @@ void drain_events(kl_ctx *c) {
 
 void soft_reset(kl_ctx *c) { c->frame = 0; c->camera_change = true; }
 
-FrameDev make_frame(const kl_ctx *c, uint32_t first_frame, uint32_t nslots) {
+// `nframes` frames from first_frame on: sub_samples() slots each
+FrameDev make_frame(const kl_ctx *c, uint32_t first_frame, uint32_t nframes) {
     FrameDev f; std::memset(&f, 0, sizeof f);
     // projection frame of RawFrame.glsl:418-420, evaluated once on the host with the same fp32 operations
     v3 pos = V(c->cam.pos[0], c->cam.pos[1], c->cam.pos[2]);
@@ -277,12 +287,14 @@ FrameDev make_frame(const kl_ctx *c, uint32_t first_frame, uint32_t nslots) {
     f.pv[0] = pv.x; f.pv[1] = pv.y; f.pv[2] = pv.z;
     f.width = c->width; f.height = c->height; f.npl = c->npl;
     f.rank = c->rank; f.world = c->world; f.band_rows = c->band_rows;
-    f.mode = c->mode; f.first_frame = first_frame; f.nslots = nslots;
+    f.mode = c->mode; f.first_frame = first_frame;
+    f.spp2 = sub_samples(c); f.spp = f.spp2 == 1u ? 1u : std::max(1u, c->params.spp_grid); f.nslots = nframes * f.spp2;
     f.max_bounces = c->params.max_bounces; f.max_frames = c->params.max_frames;
     f.eps = c->params.eps; f.max_dist = c->params.max_dist;
     f.ao_length = c->params.ao_length; f.hdri_strength = c->params.hdri_strength;
     f.nseg = KL_QUEUE_SEGMENTS; f.segcap = c->segcap;
     fastdiv_make(std::max(c->npl, 1u), f.div_npl); fastdiv_make(c->width, f.div_width); fastdiv_make(c->band_rows, f.div_band);
+    fastdiv_make(f.spp2, f.div_spp2); fastdiv_make(f.spp, f.div_spp);
     return f;
 }
 
@@ -324,10 +336,11 @@ struct Bracket {
     ~Bracket() { if (a && b && hipEventRecord(b, s) == hipSuccess) c->pending.push_back({a, b, kind}); }
 };
 
-// one wavefront batch on lane L: frames [first, first+nslots) traced together, then accumulated in order.
+// one wavefront batch on lane L: frames [first, first+nframes) traced together, then accumulated in order.
 // `after` (may be null): the accumulate of the batch before this one, which this batch's accumulate follows.
-kl_status render_batch(kl_ctx *c, BatchLane &L, hipEvent_t after, uint32_t first, uint32_t nslots, bool camera_change) {
-    FrameDev f = make_frame(c, first, nslots);
+kl_status render_batch(kl_ctx *c, BatchLane &L, hipEvent_t after, uint32_t first, uint32_t nframes, bool camera_change) {
+    FrameDev f = make_frame(c, first, nframes);
+    const uint32_t nslots = f.nslots;
     const uint32_t B = c->params.max_bounces;
     // count[b] / head[b]: one word per queue segment and bounce
     const size_t S = (size_t)KL_QUEUE_SEGMENTS * CTR_STRIDE;      // words per bounce level
@@ -340,19 +353,19 @@ kl_status render_batch(kl_ctx *c, BatchLane &L, hipEvent_t after, uint32_t first
     KL_HIP(c, hipMemsetAsync(head, 0, (size_t)(levels + 1) * S * sizeof(uint32_t), L.stream));
     // Every frame of the batch starts with the same camera ray per pixel: unless told otherwise, that ray is traced
     // once (a one-frame queue of its own) and generate copies its hit to the paths of all frames.
-    const bool shared = nslots > 1 && c->params.trace_primary_per_frame == 0;
+    const bool shared = nframes > 1 && c->params.trace_primary_per_frame == 0;
     // The flat primitives (scene-spanning ones kept out of the tree) are tested by the kernel that makes a ray, generate
     // or shade, while the ray is in registers, and the hit travels in the ray's queue entry; only the stand-alone
     // compaction moves rays afterwards and needs the separate flat pass.
     const bool pflat = use_bvh(c) && scene_has_flat(c->sc) && fused && !c->flat_separate;
     if (shared) {
-        FrameDev f1 = f; f1.nslots = 1; f1.segcap = c->segcap1;
+        FrameDev f1 = f; f1.nslots = f.spp2; f1.segcap = c->segcap1;       // one frame's worth of camera rays
         uint32_t *count1 = count + (size_t)(B + 2) * S, *head1 = head + (size_t)(B + 2) * S;
         KL_HIP(c, hipMemsetAsync(count1, 0, S * sizeof(uint32_t), L.stream));
         KL_HIP(c, hipMemsetAsync(head1, 0, S * sizeof(uint32_t), L.stream));
         RayQueue q1 = { L.p_od.p, L.p_dt.p, nullptr, L.p_uv.p };
         { Bracket t(c, L.stream, EV_GENERATE); launch_generate(L.stream, c->lc, c->sc, f1, q1, count1, pflat); }
-        kl_status s1 = timed_intersect(c, L, f1, q1, count1, head1, c->npl, pflat);
+        kl_status s1 = timed_intersect(c, L, f1, q1, count1, head1, c->npl * f.spp2, pflat);
         if (s1 != KL_OK) return s1;
         { Bracket t(c, L.stream, EV_GENERATE); launch_generate(L.stream, c->lc, c->sc, f, q[0], count, false, q1, c->segcap1); }
     } else {
@@ -440,7 +453,7 @@ kl_status kl_default_params(kl_params *p) {
     std::memset(p, 0, sizeof *p);
     p->max_bounces = 32; p->max_frames = 30; p->eps = 0.001f; p->max_dist = 5000.0f;
     p->ao_length = 1.0f; p->hdri_strength = 1.0f; p->accel = KL_ACCEL_AUTO;
-    p->frames_in_flight = 0; p->fused_compaction = 1; p->collect_stats = 0; p->profile_kernels = 0; p->batch_lanes = 0; p->trace_primary_per_frame = 0;
+    p->spp_grid = 1; p->frames_in_flight = 0; p->fused_compaction = 1; p->collect_stats = 0; p->profile_kernels = 0; p->batch_lanes = 0; p->trace_primary_per_frame = 0;
     return KL_OK;
 }
 kl_status kl_default_camera(kl_camera *cam) {
@@ -552,6 +565,7 @@ kl_status kl_set_params(kl_ctx *c, const kl_params *p) {
     if (p->accel > KL_ACCEL_BVH) return fail(c, KL_E_INVALID, "bad accel");
     if (p->bvh_builder > KL_BUILD_GPU_LBVH) return fail(c, KL_E_INVALID, "bad bvh_builder");
     if (p->batch_lanes > KL_MAX_BATCH_LANES) return fail(c, KL_E_LIMIT, "batch_lanes must be <= 4");
+    if (p->spp_grid > 8) return fail(c, KL_E_LIMIT, "spp_grid must be <= 8");
     if (!(p->max_dist > 0.0f) || !(p->eps >= 0.0f)) return fail(c, KL_E_INVALID, "bad eps/max_dist");
     KL_HIP(c, hipSetDevice(c->device));
     KL_HIP(c, hipStreamSynchronize(c->stream));
@@ -843,7 +857,7 @@ static kl_status kl_render_frames_body(kl_ctx *c, uint32_t n, uint32_t first_fra
             if (after) KL_HIP(c, hipStreamWaitEvent(L.stream, after, 0));
             launch_accumulate(L.stream, c->lc, f, L.d_raw.p, c->d_acc.p, c->d_last_raw.p, false, c->accum_mode);
         } else {
-            k = std::min(left, std::min(per_batch, c->slots));
+            k = std::min(left, std::min(per_batch, std::max(1u, c->slots / sub_samples(c))));
             if (mf) k = std::min(k, mf - frame);
             if ((s = render_batch(c, L, after, frame, k, c->camera_change)) != KL_OK) {
                 // the context stream still resumes after whatever the lanes were given, and the call's events go back
@@ -856,7 +870,7 @@ static kl_status kl_render_frames_body(kl_ctx *c, uint32_t n, uint32_t first_fra
                 if (eb) c->free_events.push_back(eb);
                 return s;
             }
-            c->paths_total += (uint64_t)k * c->npl;
+            c->paths_total += (uint64_t)k * c->npl * sub_samples(c);
         }
         if (lanes > 1) { KL_HIP(c, hipEventRecord(L.done, L.stream)); last_done = L.done; }
         last_lane = l; lane_used[l] = true;

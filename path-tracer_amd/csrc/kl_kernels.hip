@@ -237,8 +237,8 @@ __device__ __forceinline__ uint32_t dealt_slot(uint32_t i, uint32_t nseg, uint32
 // ------------------------------------------------------------------ generate
 // RF:417-422 with the uv arithmetic of RF:428-429,436; one thread per (slot, pixel). Every ray leaves with the
 // closest hit so far in its queue entry:
-//   seed.od != null: every frame of a batch starts with the same camera ray per pixel (the shader adds no sub-pixel
-//     jitter, RF:436 with SPP = 1), so that ray was traced once, in the one-frame queue `seed` of segment capacity
+//   seed.od != null: every frame of a batch starts with the same camera rays per pixel (the shader's sub-pixel offsets,
+//     RF:436, do not depend on the frame), so they were traced once, in the one-frame queue `seed` of segment capacity
 //     `seed_segcap`, and its hit is copied into the entry of each frame's path;
 //   else flat != 0: the camera ray is tested against the flat primitives here, while it is in registers;
 //   else: a miss (an intersect kernel that looks at every primitive follows).
@@ -262,16 +262,18 @@ __global__ __launch_bounds__(256) void k_generate(SceneDev sc, FrameDev f, RayQu
         local_to_pixel(f, li, x, y);
         float ux = (((float)x + 0.5f) - 1.0f - rx / 2.0f) / m;
         float uy = (((float)y + 0.5f) - 1.0f - ry / 2.0f) / m;
-        if (f.mode != KL_MODE_Z) {               // RF:436 with SPP = 1
+        const uint32_t sub = slot - fastdiv(slot, f.div_spp2) * f.spp2;      // which sub-sample of the SPP x SPP grid (0 at SPP = 1)
+        if (f.mode != KL_MODE_Z) {               // RF:436: uv - 0.5 * pixel_size + vec2(x / SPP, y / SPP) * pixel_size, x outer, y inner
+            const uint32_t sx = fastdiv(sub, f.div_spp), sy = sub - sx * f.spp;
             float psx = 1.0f / rx, psy = 1.0f / ry;
-            ux = (ux - 0.5f * psx) + (0.0f / 1.0f) * psx;
-            uy = (uy - 0.5f * psy) + (0.0f / 1.0f) * psy;
+            ux = (ux - 0.5f * psx) + ((float)sx / (float)f.spp) * psx;
+            uy = (uy - 0.5f * psy) + ((float)sy / (float)f.spp) * psy;
         }
         v3 d = normalize(pc + pu * ux + pv * uy - pos);
         const uint32_t dst = dealt_slot(i, f.nseg, f.segcap);
         float t = f.max_dist; uint32_t ref = REF_MISS;
         if (seed.od) {
-            const uint32_t src = dealt_slot(li, f.nseg, seed_segcap);    // this pixel's ray in the one-frame queue
+            const uint32_t src = dealt_slot(sub * f.npl + li, f.nseg, seed_segcap);    // this pixel's (sub-sample's) ray in the one-frame queue
             const float4 sdt = seed.dt[src];
             t = sdt.z; ref = __float_as_uint(sdt.w);
             q.uv[dst] = seed.uv[src];                                   // meaningful only for textured primitives; copied blindly
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(256, KL_SHADE_MIN_WAVES) void k_shade(SceneDev sc_b
         if (valid) {
             uint32_t slot = fastdiv(path, f.div_npl), li = path - slot * f.npl, px, py;
             local_to_pixel(f, li, px, py);
-            f4 r = rand4(px, py, f.first_frame + slot);
+            f4 r = rand4(px, py, f.first_frame + fastdiv(slot, f.div_spp2));     // every sub-sample of a frame sees the same numbers
             if (MODE == KL_MODE_Z) {
                 if (!(t >= f.max_dist)) { float z = 1.0f - fminf(t / 50.0f, 0.9f); col = V(z, z, z); }
             } else if (MODE == KL_MODE_AO) {
@@ -881,10 +883,22 @@ __global__ __launch_bounds__(256) void k_accumulate(FrameDev f, const float4 *ra
     for (uint32_t li = blockIdx.x * blockDim.x + threadIdx.x; li < f.npl; li += gridDim.x * blockDim.x) {
         float4 a = acc[li];
         float4 r = make_float4(0, 0, 0, 1);
-        for (uint32_t s = 0; s < f.nslots; s++) {
+        const uint32_t nframes = fastdiv(f.nslots, f.div_spp2);
+        for (uint32_t s = 0; s < nframes; s++) {
             const uint32_t frame = f.first_frame + s;
             const bool frozen = f.max_frames != 0u && frame >= f.max_frames;
-            r = frozen ? a : raw[(size_t)s * f.npl + li];
+            if (frozen) r = a;
+            else if (f.spp2 == 1u) r = raw[(size_t)s * f.npl + li];
+            else {
+                // RF:433-440 / :445-453: col = 0; col += each sub-sample in x-outer, y-inner order; col /= float(SPP * SPP)
+                float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+                for (uint32_t k = 0; k < f.spp2; k++) {
+                    const float4 c = raw[((size_t)s * f.spp2 + k) * f.npl + li];
+                    cx += c.x; cy += c.y; cz += c.z;
+                }
+                const float n = (float)f.spp2;
+                r = make_float4(cx / n, cy / n, cz / n, 1.0f);
+            }
             if (accum_mode == KL_ACCUM_SUM) {
                 // a frozen frame leaves the mean where it is, i.e. adds no term to the sum
                 if (!frozen) { a.x += r.x; a.y += r.y; a.z += r.z; }

@@ -120,13 +120,14 @@ struct FrameDev {
     uint32_t npl;                       // pixels owned by this context (local rows x width)
     uint32_t rank, world, band_rows;    // row-band partition
     uint32_t mode;
-    uint32_t first_frame, nslots;       // frames [first_frame, first_frame + nslots) are in flight
+    uint32_t first_frame, nslots;       // slots in flight: spp2 consecutive slots per frame, frames from first_frame on
+    uint32_t spp, spp2;                 // sub-pixel grid of RawFrame.glsl:37 (SPP) and its square: slot = frame slot * spp2 + (x * spp + y)
     uint32_t max_bounces, max_frames;
     float eps, max_dist, ao_length, hdri_strength;
     uint32_t nseg, segcap;              // queue segmentation, see RayQueue
     uint32_t all_uv;                    // 1: every hit stores its (u, v), not only those whose shading reads them (caller rays)
     // division by npl, width and band_rows as multiply-high + add + shift (exact for dividends below 2^31)
-    uint32_t div_npl[2], div_width[2], div_band[2];
+    uint32_t div_npl[2], div_width[2], div_band[2], div_spp2[2], div_spp[2];
 };
 // n / d for n < 2^31 with {m, s} = fastdiv_make(d): s = ceil(log2 d), m = floor(2^(32+s) / d) + 1 - 2^32
 __host__ __device__ inline void fastdiv_make(uint32_t d, uint32_t out[2]) {

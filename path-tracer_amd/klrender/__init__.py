@@ -44,7 +44,7 @@ class Params(C.Structure):
                 ("max_dist", C.c_float), ("ao_length", C.c_float), ("hdri_strength", C.c_float),
                 ("accel", C.c_uint32), ("frames_in_flight", C.c_uint32), ("fused_compaction", C.c_uint32),
                 ("collect_stats", C.c_uint32), ("profile_kernels", C.c_uint32), ("batch_lanes", C.c_uint32),
-                ("trace_primary_per_frame", C.c_uint32), ("bvh_builder", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+                ("trace_primary_per_frame", C.c_uint32), ("bvh_builder", C.c_uint32), ("spp_grid", C.c_uint32), ("reserved", C.c_uint32 * 1)]
 
 
 class Counters(C.Structure):

@@ -24,7 +24,24 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "glsl_ref")
 TMP = os.environ.get("TMPDIR", "/tmp")
 
 
-def run_ref(w, h, mode, first_frame, nframes, textures, bounces=None, samples=None, acc=False):
+# camera poses beyond the default one (position, front, up), chosen for the branches the default view reaches rarely or never
+POSES = {
+    # close on the glass sphere (centre (-1, 1.5, -1), radius 0.2): the inside branch (RawFrame.glsl:308-309,384-387) and the
+    # missing total-internal-reflection case (:388-399: sqrt of a negative -> NaN -> reflect)
+    "glass": dict(cam=((-1, 1.5, -0.45), (0, 0, -1), (0, 1, 0)), w=160, h=90),
+    # camera ON the right wall's plane (x = 2.66) looking along it, odd image width: the ZDepth column with uv.x == 0 has
+    # dot(dir, nor) == 0 for both side walls: t = -0/0 = NaN for the right one, +-inf for the left one (:225-226), and every
+    # other ray grazes the walls and the floor
+    "grazing": dict(cam=((2.66, 1, 4), (0, 0, -1), (0, 1, 0)), w=161, h=91),
+    # camera inside the glass sphere: the first hit is an inside hit (:308), the first bounce leaves the glass
+    "inside": dict(cam=((-1, 1.5, -1.05), (0, 0, -1), (0, 1, 0)), w=160, h=90),
+    # straight down at the floor, 64 x 64 (powers of two keep the pixel arithmetic exact): the path-traced ray of pixel
+    # (33, 33) is exactly -normal of the floor, so tangent = normalize(cross(dir, N)) is NaN (:366) and travels down the path
+    "down": dict(cam=((0.5, 1, 0), (0, -1, 0), (0, 0, -1)), w=64, h=64),
+}
+
+
+def run_ref(w, h, mode, first_frame, nframes, textures, bounces=None, samples=None, acc=False, cam=None, spp=None):
     raw_path = os.path.join(TMP, "kl_golden_raw.f32")
     acc_path = os.path.join(TMP, "kl_golden_acc.f32")
     cmd = [BIN, "--shaders", os.path.join(REF, "resources", "Shaders"), "--w", str(w), "--h", str(h),
@@ -39,6 +56,10 @@ def run_ref(w, h, mode, first_frame, nframes, textures, bounces=None, samples=No
         cmd += ["--bounces", str(bounces)]
     if samples is not None:
         cmd += ["--samples", str(samples)]
+    if spp is not None:
+        cmd += ["--spp", str(spp)]
+    if cam is not None:
+        cmd += ["--cam"] + [repr(float(v)) for part in cam for v in part]
     res = subprocess.run(cmd, check=True, stderr=subprocess.PIPE, text=True)
     accum = np.fromfile(acc_path, dtype=np.float32).reshape(h, w, 4)
     if acc:
@@ -46,9 +67,38 @@ def run_ref(w, h, mode, first_frame, nframes, textures, bounces=None, samples=No
     return np.fromfile(raw_path, dtype=np.float32).reshape(nframes, h, w, 4), res.stderr
 
 
+def poses(tex, manifest):
+    """Z / AO / path-traced frames {0, 5} at every pose of POSES, an 8-bounce path-traced frame at the glass pose, and the
+    SPP = 2 sub-pixel grid (RawFrame.glsl:37,434-440,446-453) at the default pose and at the glass pose."""
+    out = {}
+    for name, ps in POSES.items():
+        for mode, mname in ((2, "z"), (0, "ao"), (1, "pt")):
+            for f in (0, 5):
+                img, _ = run_ref(ps["w"], ps["h"], mode, f, 1, tex, samples=64, cam=ps["cam"])
+                out["%s_%s_f%d" % (name, mname, f)] = img[0, :, :, :3].copy()
+    g = POSES["glass"]
+    img, _ = run_ref(g["w"], g["h"], 1, 5, 1, tex, samples=64, bounces=8, cam=g["cam"])
+    out["glass_pt8_f5"] = img[0, :, :, :3].copy()
+    np.savez_compressed(os.path.join(HERE, "poses.npz"), **out)
+    manifest["files"]["poses.npz"] = {"poses": {k: {"cam": v["cam"], "w": v["w"], "h": v["h"]} for k, v in POSES.items()},
+                                      "frames": [0, 5], "keys": sorted(out)}
+    out = {}
+    for mode, mname in ((0, "ao"), (1, "pt")):
+        for f in (0, 5):
+            img, _ = run_ref(64, 36, mode, f, 1, tex, samples=64, spp=2)
+            out["default_%s_f%d" % (mname, f)] = img[0, :, :, :3].copy()
+    img, _ = run_ref(g["w"], g["h"], 1, 5, 1, tex, samples=64, spp=2, cam=g["cam"])
+    out["glass_pt_f5"] = img[0, :, :, :3].copy()
+    acc, _ = run_ref(64, 36, 1, 0, 4, tex, samples=64, spp=2, acc=True)
+    out["default_pt_mean4"] = acc[:, :, :3].copy()
+    np.savez_compressed(os.path.join(HERE, "spp2.npz"), **out)
+    manifest["files"]["spp2.npz"] = {"spp": 2, "declared_patch": "#define SPP 1 -> 2", "keys": sorted(out)}
+
+
 def main():
     if not os.path.exists(BIN):
         sys.exit("build oracle/_ref/glsl_ref first: make -C oracle ref")
+    only_poses = len(sys.argv) > 1 and sys.argv[1] == "poses"     # adds poses.npz / spp2.npz and leaves the other files alone
     # The two data files the reference host loads (GLSL_Renderer.cpp:237,240), decoded with the
     # stb_image.h the reference vendors (what Image::f_load calls), kept as test data. Background.png
     # is a real PNG (lossless: any decoder gives these bytes) and is kept as a file; "Texture.png" is
@@ -70,6 +120,13 @@ def main():
            "albedo": (tx_raw, tx.shape[1], tx.shape[0], tx.shape[2])}
     manifest = {"generator": "tests/golden/make_golden.py", "harness": "oracle/ref_harness.c",
                 "deviations": ["RGBA32F attachments", "vec3 col = vec3(0)", "ping-pong accumulation"], "files": {}}
+    if only_poses:
+        manifest = json.load(open(os.path.join(HERE, "MANIFEST.json")))
+        poses(tex, manifest)
+        with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
+    poses(tex, manifest)
     frames = [0, 1, 5, 15]
     info = ""
     for (w, h) in ((64, 36), (160, 90)):

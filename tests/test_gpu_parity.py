@@ -74,16 +74,17 @@ def test_builtin_against_llvmpipe_goldens(size, textures):
                 continue
             got = render_raw(r, modes[name], int(f))[..., :3]
             ref = g[key]
+            # the budgets of tests/test_oracle_golden.py::test_builtin_frames (measured worst case + a small margin)
             if name == "z":
                 assert_bitexact(got, ref, key)                  # ZDepth reproduces llvmpipe bit for bit
             elif name == "ao":
-                assert frac_within_rel(got, ref) >= 0.999, key  # 1e-4 relative, outlier budget 0.1 %
+                assert frac_within_rel(got, ref) == 1.0 and np.abs(got - ref).max() <= 3e-6, key   # every pixel within 1e-4 relative
             else:
-                assert frac_within_rel(got, ref) >= 0.99 and mae_clamped(got, ref) <= 5e-4, key
+                assert frac_within_rel(got, ref) >= 0.996 and mae_clamped(got, ref) <= 1.5e-4, key
     with make_renderer(w, h, None, max_frames=0) as r:          # 1x1 white textures
         for f in (0, 5):
             got = render_raw(r, kl.MODE_PT, f)[..., :3]
-            assert frac_within_rel(got, g["ptwhite_f%d" % f]) >= 0.999
+            assert frac_within_rel(got, g["ptwhite_f%d" % f]) >= 0.9998
 
 
 def test_config1_16spp(textures, oracle_builtin):
@@ -106,7 +107,8 @@ def test_config1_16spp(textures, oracle_builtin):
     assert_bitexact(acc, want, "config 1 mean")
     assert cn.paths == 640 * 360 * 16 and cn.rays == ocn.rays      # same ray count as the CPU walk
     ref = golden("config1_pt_640x360_16spp.npz")["acc"]
-    assert mae_clamped(acc[..., :3], ref) <= 1e-4                  # stated PT bound vs the reference shader
+    from test_oracle_golden import CONFIG1_MAE
+    assert mae_clamped(acc[..., :3], ref) <= CONFIG1_MAE           # stated PT bound vs the reference shader (measured 3.0e-6)
 
 
 def test_converged_4096spp(textures, oracle_builtin):
@@ -129,7 +131,7 @@ def test_converged_4096spp(textures, oracle_builtin):
     assert_bitexact(acc, want, "4096-frame mean")
 
 
-@pytest.mark.parametrize("mode,name,budget", [(kl.MODE_Z, "z", 0.9999), (kl.MODE_AO, "ao", 0.99)])
+@pytest.mark.parametrize("mode,name,budget", [(kl.MODE_Z, "z", 1.0), (kl.MODE_AO, "ao", 0.9999)])
 def test_config2_1080p(mode, name, budget, textures, oracle_builtin):
     """BASELINE config 2: 1920x1080, frame 0, ZDepth and AO on one GPU"""
     with make_renderer(1920, 1080, textures, max_frames=0) as r:
@@ -139,7 +141,7 @@ def test_config2_1080p(mode, name, budget, textures, oracle_builtin):
     assert_bitexact(got, want, "config 2 " + name)
     g = golden("config2_1920x1080_f0.npz")
     assert frac_within_rel(got[3::8, :, 0], g[name + "_rows"]) >= budget
-    assert abs(got[..., 0].astype(np.float64).mean() - float(g[name + "_mean"])) <= 1e-6
+    assert abs(got[..., 0].astype(np.float64).mean() - float(g[name + "_mean"])) <= 1e-9
 
 
 def test_batching_and_compaction_do_not_change_results(textures):
@@ -165,13 +167,13 @@ def test_samples_freeze_and_bounce_cap(textures, oracle_builtin):
         acc = r.read_accum()
     p = ko.default_params(width=64, height=36, mode=ko.MODE_PT, max_frames=4)
     assert_bitexact(acc, ko.render_mean(oracle_builtin, cam, p, 6), "SAMPLES freeze")
-    assert mae_clamped(acc[..., :3], golden("pt_64x36_freeze4_6frames.npz")["acc"]) <= 1e-4
+    assert mae_clamped(acc[..., :3], golden("pt_64x36_freeze4_6frames.npz")["acc"]) <= 2e-5
     with make_renderer(160, 90, textures, max_bounces=8) as r:
         r.render_frames(4)
         acc = r.read_accum()
     p = ko.default_params(width=160, height=90, mode=ko.MODE_PT, max_frames=30, max_bounces=8)
     assert_bitexact(acc, ko.render_mean(oracle_builtin, cam, p, 4), "8-bounce cap")
-    assert mae_clamped(acc[..., :3], golden("pt_160x90_4spp_8bounce.npz")["acc"]) <= 1e-4
+    assert mae_clamped(acc[..., :3], golden("pt_160x90_4spp_8bounce.npz")["acc"]) <= 2e-5
 
 
 def test_reset_rules(textures):
@@ -212,6 +214,79 @@ def test_other_camera_and_params(textures, oracle_builtin):
         p = ko.default_params(width=120, height=80, mode=KO_MODE[mode], max_frames=0, ao_length=0.5,
                               hdri_strength=1.5, eps=0.002, max_dist=40.0)
         assert_bitexact(got, oracle_builtin.render_raw(cam, p, 3), "camera/params mode %d" % mode)
+
+
+def kl_camera(ocam):
+    return kl.Camera.from_buffer_copy(bytes(ocam))
+
+
+@pytest.mark.parametrize("pose", ["down", "glass", "grazing", "inside"])
+def test_other_camera_poses_against_the_reference_shader(pose, textures, oracle_builtin):
+    """Close on the glass sphere, along a wall from on its plane (quad t = NaN / inf), inside the glass sphere, straight down
+    (NaN tangent): the HIP path against the reference shader's own images at those poses (budgets shared with the oracle's
+    test) and bit for bit against the oracle, all three modes, both intersect back ends."""
+    from test_oracle_golden import check_pose_image, pose_camera
+    g = golden("poses.npz")
+    cam, w, h = pose_camera(pose)
+    modes = {"z": kl.MODE_Z, "ao": kl.MODE_AO, "pt": kl.MODE_PT, "pt8": kl.MODE_PT}
+    for accel in (kl.ACCEL_BRUTE, kl.ACCEL_BVH):
+        with make_renderer(w, h, textures, max_frames=0, accel=accel) as r:
+            r.set_camera(kl_camera(cam))
+            for key in sorted(k for k in g.files if k.startswith(pose + "_")):
+                mode, f = key.split("_")[1], int(key.split("_f")[1])
+                bounces = 8 if mode == "pt8" else 32
+                r.update_params(max_bounces=bounces)
+                got = render_raw(r, modes[mode], f)
+                p = ko.default_params(width=w, height=h, mode=KO_MODE[modes[mode]], max_frames=0, max_bounces=bounces)
+                assert_bitexact(got, oracle_builtin.render_raw(cam, p, f), "%s accel %d" % (key, accel))
+                check_pose_image(key, got[..., :3], g[key])
+
+
+def test_spp_grid(textures, oracle_builtin):
+    """kl_params::spp_grid = 2 (#define SPP 2, RawFrame.glsl:37,434-440,446-453): against the reference shader run with that
+    define rewritten, bit for bit against the oracle, with the camera rays traced per frame and shared by a batch's frames,
+    through both intersect back ends; ZDepth ignores the grid; frames_in_flight counts frames, not sub-samples."""
+    from test_oracle_golden import check_spp2_image, pose_camera
+    g = golden("spp2.npz")
+    modes = {"ao": kl.MODE_AO, "pt": kl.MODE_PT}
+    for key in sorted(g.files):
+        pose, mode, f = key.split("_")
+        cam, w, h = pose_camera(pose) if pose != "default" else (ko.default_camera(), 64, 36)
+        p = ko.default_params(width=w, height=h, mode=KO_MODE[modes[mode]], max_frames=0, spp=2)
+        with make_renderer(w, h, textures, max_frames=0, spp_grid=2) as r:
+            r.set_camera(kl_camera(cam))
+            r.set_mode(modes[mode])
+            if f == "mean4":
+                want = ko.render_mean(oracle_builtin, cam, p, 4)
+                for accel, fif, per_frame in ((kl.ACCEL_BRUTE, 0, 0), (kl.ACCEL_BVH, 0, 1), (kl.ACCEL_BVH, 3, 0), (kl.ACCEL_BRUTE, 1, 0)):
+                    r.update_params(accel=accel, frames_in_flight=fif, trace_primary_per_frame=per_frame)
+                    r.reset(); r.reset_counters()
+                    r.render_frames(4)
+                    got = r.read_accum()
+                    assert_bitexact(got, want, "spp 2 mean, accel %d fif %d per-frame %d" % (accel, fif, per_frame))
+                    assert r.counters().paths == 4 * w * h * 4
+            else:
+                r.render_frames(1, first_frame=int(f[1:]))
+                got = r.read_raw()
+                assert_bitexact(got, oracle_builtin.render_raw(cam, p, int(f[1:])), "spp 2 " + key)
+            check_spp2_image(key, got[..., :3], g[key])
+    with make_renderer(64, 36, textures, max_frames=0, spp_grid=2) as r:
+        z2 = render_raw(r, kl.MODE_Z, 0)
+        r.update_params(spp_grid=1)
+        assert_bitexact(render_raw(r, kl.MODE_Z, 0), z2, "ZDepth with and without the grid")
+        with pytest.raises(kl.KlError):
+            r.update_params(spp_grid=9)
+    # a triangle scene through the tree, spp 3, sample-range sums: the grid with every other feature on
+    s, q, t, m = kl.synth_scene(blobs=6, tris_per_blob=200, analytic_spheres=5, seed=4)
+    osc = ko.Scene(s, q, t, m)
+    osc.set_texture(ko.TEX_HDRI, textures["hdri"]); osc.set_texture(ko.TEX_ALBEDO, textures["albedo"])
+    p = ko.default_params(width=48, height=27, mode=ko.MODE_PT, max_frames=0, max_bounces=6, use_bvh=1, spp=3)
+    with kl.Renderer(48, 27) as r:
+        r.upload_scene(s, q, t, m)
+        r.upload_texture(kl.TEX_HDRI, textures["hdri"]); r.upload_texture(kl.TEX_ALBEDO, textures["albedo"])
+        r.update_params(max_frames=0, max_bounces=6, spp_grid=3, accel=kl.ACCEL_BVH)
+        r.render_frames(5)
+        assert_bitexact(r.read_accum(), ko.render_mean(osc, ko.default_camera(), p, 5), "spp 3, triangle scene")
 
 
 def test_resolve_matches_present_pass(textures):

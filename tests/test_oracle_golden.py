@@ -17,6 +17,8 @@ from conftest import frac_within_rel, golden, mae_clamped
 # clamp(x,0,1), largest absolute difference, relative tolerance and the fraction of pixels that must meet it.
 # Measured, oracle vs llvmpipe: 3.0e-6, 2.0e-3, 99.73 % (82.8 % within 1e-4, 43 % of values bit-identical).
 CONVERGED_MAE, CONVERGED_MAX_ABS, CONVERGED_REL, CONVERGED_FRAC = 1e-5, 5e-3, 1e-3, 0.99
+# config 1 (640x360, 16-frame mean): stated bound on the MAE of clamp(x,0,1) against the reference shader; measured 3.0e-6
+CONFIG1_MAE = 1e-5
 
 MODES = {"z": ko.MODE_Z, "ao": ko.MODE_AO, "pt": ko.MODE_PT, "ptwhite": ko.MODE_PT}
 
@@ -39,16 +41,21 @@ def test_builtin_frames(size, oracle_builtin, white_scene):
         assert np.all(out[..., 3] == 1.0)
         out, ref = out[..., :3], g[key]
         bitexact = np.mean(out.view(np.uint32) == ref.view(np.uint32))
+        # budgets = the measured worst case over these frames plus a small margin (so that a regression ten times
+        # today's disagreement fails): ZDepth identical; AO every pixel within 1e-4 relative, max |d| 1.1e-6, >= 98.7 %
+        # of values bit-identical; white-texture path tracing 99.993 % of pixels within 1e-4; with the real textures
+        # 99.72 % (llvmpipe's atan/acos move an environment texel now and then), MAE of clamp(x,0,1) 7.9e-5
         if name == "z":
             assert bitexact == 1.0, key                       # no transcendental on this path
         elif name == "ao":
-            assert frac_within_rel(out, ref) >= 0.999, key
-            assert bitexact >= 0.97, key
+            assert frac_within_rel(out, ref) == 1.0, key
+            assert np.abs(out - ref).max() <= 3e-6, key
+            assert bitexact >= 0.98, key
         elif name == "ptwhite":
-            assert frac_within_rel(out, ref) >= 0.999, key
+            assert frac_within_rel(out, ref) >= 0.9998, key
         else:
-            assert frac_within_rel(out, ref) >= 0.99, key
-            assert mae_clamped(out, ref) <= 5e-4, key
+            assert frac_within_rel(out, ref) >= 0.996, key
+            assert mae_clamped(out, ref) <= 1.5e-4, key
 
 
 def test_config1_16spp_mean(oracle_builtin):
@@ -57,8 +64,8 @@ def test_config1_16spp_mean(oracle_builtin):
     p = ko.default_params(width=640, height=360, mode=ko.MODE_PT, max_frames=30)
     cn = ko.Counters()
     acc = ko.render_mean(oracle_builtin, ko.default_camera(), p, 16, counters=cn)[..., :3]
-    assert mae_clamped(acc, ref) <= 1e-4          # measured 3e-6
-    assert frac_within_rel(acc, ref) >= 0.94      # measured 0.962: any of 16 frames may flip a texel
+    assert mae_clamped(acc, ref) <= CONFIG1_MAE   # measured 3.0e-6
+    assert frac_within_rel(acc, ref) >= 0.955     # measured 0.962: any of 16 frames may flip a texel
     assert 5.7 < cn.rays / cn.paths < 6.1         # ~5.9 rays per path on this scene
 
 
@@ -78,7 +85,7 @@ def test_bounce_cap_parameter(oracle_builtin):
     ref = golden("pt_160x90_4spp_8bounce.npz")["acc"]
     p = ko.default_params(width=160, height=90, mode=ko.MODE_PT, max_frames=30, max_bounces=8)
     acc = ko.render_mean(oracle_builtin, ko.default_camera(), p, 4)[..., :3]
-    assert mae_clamped(acc, ref) <= 1e-4 and frac_within_rel(acc, ref) >= 0.98
+    assert mae_clamped(acc, ref) <= 2e-5 and frac_within_rel(acc, ref) >= 0.99      # measured 5.8e-6, 0.9946
 
 
 def test_samples_freeze(oracle_builtin):
@@ -86,10 +93,11 @@ def test_samples_freeze(oracle_builtin):
     ref = golden("pt_64x36_freeze4_6frames.npz")["acc"]
     p = ko.default_params(width=64, height=36, mode=ko.MODE_PT, max_frames=4)
     acc = ko.render_mean(oracle_builtin, ko.default_camera(), p, 6)[..., :3]
-    assert mae_clamped(acc, ref) <= 1e-4 and frac_within_rel(acc, ref) >= 0.98
+    assert mae_clamped(acc, ref) <= 2e-5 and frac_within_rel(acc, ref) >= 0.985     # measured 4.7e-6, 0.9909
 
 
-@pytest.mark.parametrize("name,mode,budget", [("z", ko.MODE_Z, 0.9999), ("ao", ko.MODE_AO, 0.99)])
+# measured: ZDepth every value bit-identical, AO 99.9996 % of pixels within 1e-4 relative (max |d| 2.4e-6)
+@pytest.mark.parametrize("name,mode,budget", [("z", ko.MODE_Z, 1.0), ("ao", ko.MODE_AO, 0.9999)])
 def test_config2_1080p(name, mode, budget, oracle_builtin):
     """BASELINE config 2: 1920x1080, frame 0, ZDepth and AO (col zero-initialised)."""
     g = golden("config2_1920x1080_f0.npz")
@@ -98,8 +106,84 @@ def test_config2_1080p(name, mode, budget, oracle_builtin):
     assert np.array_equal(out[..., 0], out[..., 1]) and np.array_equal(out[..., 0], out[..., 2])
     rows = out[3::8, :, 0]
     assert frac_within_rel(rows, g[name + "_rows"]) >= budget
-    assert abs(out[..., 0].astype(np.float64).mean() - float(g[name + "_mean"])) <= 1e-6
-    assert abs(np.count_nonzero(out[..., 0]) - int(g[name + "_nonzero"])) <= 200
+    assert abs(out[..., 0].astype(np.float64).mean() - float(g[name + "_mean"])) <= 1e-9
+    assert abs(np.count_nonzero(out[..., 0]) - int(g[name + "_nonzero"])) <= 2
+
+
+# ---- other camera poses and the SPP grid (tests/golden/make_golden.py: POSES) ----
+POSES = {"glass": ((-1, 1.5, -0.45), (0, 0, -1), (0, 1, 0), 160, 90), "grazing": ((2.66, 1, 4), (0, 0, -1), (0, 1, 0), 161, 91),
+         "inside": ((-1, 1.5, -1.05), (0, 0, -1), (0, 1, 0), 160, 90), "down": ((0.5, 1, 0), (0, -1, 0), (0, 0, -1), 64, 64)}
+# path traced: fraction of pixels that must be within 1e-4 relative of the reference shader's, per pose (measured minimum over
+# frames 0 and 5: 0.99979 / 0.99236 / 0.99924 / 0.98804: the grazing and straight-down views are nearly all environment and
+# wall pixels, where a texel flipped by llvmpipe's atan/acos shows) and bound on the MAE of clamp(x,0,1) (measured maxima
+# 4.1e-5 / 8.1e-5 / 1.9e-5 / 2.4e-4)
+POSE_PT_BUDGET = {"glass": (0.9993, 1e-4), "grazing": (0.991, 2e-4), "inside": (0.9985, 6e-5), "down": (0.986, 5e-4)}
+
+
+def pose_camera(name):
+    pos, front, up, w, h = POSES[name]
+    cam = ko.default_camera()
+    for k in range(3):
+        cam.pos[k], cam.front[k], cam.up[k] = pos[k], front[k], up[k]
+    return cam, w, h
+
+
+def check_pose_image(key, out, ref):
+    """the budgets of one pose image against the reference shader's (shared by the oracle test and the GPU test)"""
+    pose, mode = key.split("_")[0], key.split("_")[1]
+    assert np.isfinite(ref).all() and np.isfinite(out).all(), key
+    if mode == "z":
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), key
+    elif mode == "ao":
+        assert frac_within_rel(out, ref) == 1.0 and np.abs(out - ref).max() <= 3e-6, key      # measured max |d| 7.2e-7
+    else:
+        frac, mae = POSE_PT_BUDGET[pose]
+        assert frac_within_rel(out, ref) >= frac, key
+        assert mae_clamped(out, ref) <= mae, key
+
+
+@pytest.mark.parametrize("pose", sorted(POSES))
+def test_other_camera_poses(pose, oracle_builtin):
+    """Close on the glass sphere (inside branch, no-TIR NaN), along a wall from ON its plane (quad t = NaN / inf), from inside
+    the glass sphere, straight down at the floor (NaN tangent): oracle vs the reference shader at each, all three modes."""
+    g = golden("poses.npz")
+    cam, w, h = pose_camera(pose)
+    for key in sorted(k for k in g.files if k.startswith(pose + "_")):
+        mode, f = key.split("_")[1], int(key.split("_f")[1])
+        p = ko.default_params(width=w, height=h, mode=MODES[mode.rstrip("8")], max_frames=0, max_bounces=8 if mode.endswith("8") else 32)
+        out = oracle_builtin.render_raw(cam, p, f)[..., :3]
+        check_pose_image(key, out, g[key])
+
+
+def test_grazing_column_really_has_parallel_rays():
+    """the ZDepth pose on the wall plane: the middle column's rays have dir.x == 0 exactly, so the side walls' plane test
+    divides by zero there (RawFrame.glsl:225): -0/0 = NaN for the wall the camera stands on, +-inf for the other"""
+    cam, w, h = pose_camera("grazing")
+    o, d = ko.camera_ray(cam, w, h, 81, 40, subpixel=False)
+    assert d[0] == 0.0 and o[0] == np.float32(2.66)
+
+
+def check_spp2_image(key, out, ref):
+    mode = key.split("_")[1]
+    if mode == "ao":
+        assert frac_within_rel(out, ref) == 1.0 and np.abs(out - ref).max() <= 3e-6, key      # measured 2.4e-7
+    else:
+        # measured: 0.9931-0.9995 of pixels within 1e-4 (four sub-samples per pixel = four chances of a flipped texel),
+        # the 4-frame mean 0.979; MAE at most 9.8e-5
+        assert frac_within_rel(out, ref) >= (0.975 if key.endswith("mean4") else 0.991), key
+        assert mae_clamped(out, ref) <= 2e-4, key
+
+
+def test_spp_grid_two(oracle_builtin):
+    """#define SPP 2 (RawFrame.glsl:37): 2 x 2 sub-samples per pixel and frame, summed in x-outer / y-inner order and divided
+    by 4 (:434-440, :446-453); the reference shader ran with that one define rewritten"""
+    g = golden("spp2.npz")
+    for key in sorted(g.files):
+        pose, mode, f = key.split("_")
+        cam, w, h = pose_camera(pose) if pose != "default" else (ko.default_camera(), 64, 36)
+        p = ko.default_params(width=w, height=h, mode=MODES[mode], max_frames=0, spp=2)
+        out = ko.render_mean(oracle_builtin, cam, p, 4) if f == "mean4" else oracle_builtin.render_raw(cam, p, int(f[1:]))
+        check_spp2_image(key, out[..., :3], g[key])
 
 
 def test_rng_known_answers():
