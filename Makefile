@@ -9,7 +9,7 @@ LIB := $(PKG)/lib/libklrender.so
 # out every fused multiply-add they want; the compiler must not add or remove any.
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
             -fvisibility=hidden -Wall -Wno-unused-function -Iinclude -I$(CSRC)
-SRCS := $(CSRC)/kl_kernels.hip $(CSRC)/kl_lbvh.hip $(CSRC)/kl_api.cpp $(CSRC)/kl_bvh.cpp $(CSRC)/kl_scene.cpp $(CSRC)/kl_mesh_io.cpp
+SRCS := $(CSRC)/kl_kernels.hip $(CSRC)/kl_lbvh.hip $(CSRC)/kl_group.hip $(CSRC)/kl_api.cpp $(CSRC)/kl_bvh.cpp $(CSRC)/kl_scene.cpp $(CSRC)/kl_mesh_io.cpp
 OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 HDRS := $(wildcard $(CSRC)/*.hpp) include/Math/kl_render.h
 
@@ -17,7 +17,7 @@ all: $(LIB) tools oracle
 
 $(LIB): $(OBJS)
 	@mkdir -p $(dir $@)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -lpthread
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -lpthread -ldl
 
 build/%.hip.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build

@@ -265,6 +265,40 @@ KL_API kl_status kl_set_accum_mode(kl_ctx *ctx, uint32_t mode);
 KL_API kl_status kl_copy_accum_to_device(kl_ctx *ctx, void *dst_device, size_t bytes);
 KL_API kl_status kl_copy_accum_from_device(kl_ctx *ctx, const void *src_device, size_t bytes);
 
+/* -- several GPUs from one process (no reference counterpart: the reference renders on the one GPU that owns its GL
+ *    context, GLSL_Renderer.cpp:164-188). A group holds one context per device and runs the one exchange step of its
+ *    partition over RCCL (xGMI), directly on the contexts' accumulation buffers:
+ *      KL_SPLIT_TILES    member r renders the row bands b with b % n == r; kl_group_gather = all-gather + un-tile:
+ *                        the image is bit-identical to one GPU's;
+ *      KL_SPLIT_SAMPLES  member r sums its share of every frame range; kl_group_gather = all-reduce(sum) + one divide:
+ *                        differs from the sequential mean by fp32 re-association only.
+ *    OR KL_EXCHANGE_COPY into `split` to exchange by device-to-device copies instead of RCCL (a rehearsal mode: members
+ *    may then share a GPU, which RCCL refuses). Scene, textures, camera and parameters go to every member through the
+ *    kl_group_* setters (or to one member through kl_group_member and the per-context calls). A group is used from one
+ *    thread at a time; librccl is loaded when the first RCCL group is created. -- */
+typedef struct kl_group kl_group;
+enum { KL_SPLIT_TILES = 0, KL_SPLIT_SAMPLES = 1, KL_EXCHANGE_COPY = 0x100 };
+KL_API kl_status kl_group_create(kl_group **out, const int32_t *devices, uint32_t n, uint32_t split,
+                                 uint32_t width, uint32_t height, uint32_t band_rows);
+KL_API kl_status kl_group_destroy(kl_group *g);
+KL_API kl_status kl_group_size(kl_group *g, uint32_t *n);
+KL_API kl_status kl_group_member(kl_group *g, uint32_t rank, kl_ctx **ctx);
+KL_API kl_status kl_group_upload_scene(kl_group *g, const kl_sphere *spheres, uint32_t n_spheres, const kl_quad *quads, uint32_t n_quads,
+                                       const kl_tri *tris, uint32_t n_tris, const kl_material *materials, uint32_t n_materials);
+KL_API kl_status kl_group_load_builtin_scene(kl_group *g);
+KL_API kl_status kl_group_upload_texture(kl_group *g, uint32_t which, const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t channels);
+KL_API kl_status kl_group_set_params(kl_group *g, const kl_params *p);
+KL_API kl_status kl_group_set_camera(kl_group *g, const kl_camera *cam);
+KL_API kl_status kl_group_set_mode(kl_group *g, uint32_t mode);
+KL_API kl_status kl_group_reset(kl_group *g);
+/* n frames from first_frame (KL_CONTINUE: after the last ones), queued on every member; returns without waiting */
+KL_API kl_status kl_group_render_frames(kl_group *g, uint32_t n, uint32_t first_frame);
+/* the exchange: afterwards every member holds the whole image (sample ranges: the mean over the frames rendered since the
+ * last reset) on its device; member 0's copy goes to rgba (height x width x 4 floats, row 0 = bottom) unless that is NULL */
+KL_API kl_status kl_group_gather(kl_group *g, float *rgba, size_t bytes);
+KL_API kl_status kl_group_image_device(kl_group *g, uint32_t rank, const float **rgba_device);
+KL_API const char *kl_group_last_error(kl_group *g);
+
 KL_API const char *kl_status_string(kl_status s);
 KL_API const char *kl_last_error(kl_ctx *ctx);
 KL_API uint32_t kl_abi_version(void);

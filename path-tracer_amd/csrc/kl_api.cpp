@@ -17,6 +17,7 @@
 
 #include "Math/kl_render.h"
 #include "kl_bvh.hpp"
+#include "kl_internal.hpp"
 #include "kl_kernels.hpp"
 #include "kl_lbvh.hpp"
 #include "kl_math.hpp"
@@ -430,6 +431,19 @@ void flat_quad_terms(const kl_quad &x, float4 *f) {
 }
 
 }  // namespace
+
+namespace kl {
+kl_status ctx_view(kl_ctx *c, CtxView *out) {
+    if (!c || !out) return KL_E_INVALID;
+    kl_status s = ensure_buffers(c);
+    if (s != KL_OK) return s;
+    out->device = c->device; out->stream = c->stream; out->acc = c->d_acc.p;
+    out->width = c->width; out->height = c->height; out->npl = c->npl; out->local_rows = c->local_rows;
+    out->rank = c->rank; out->world = c->world; out->band_rows = c->band_rows;
+    out->frame = c->frame; out->max_frames = c->params.max_frames; out->accum_mode = c->accum_mode; out->cus = c->lc.cus;
+    return KL_OK;
+}
+}  // namespace kl
 
 extern "C" {
 

@@ -5,6 +5,10 @@
 //   kl_bench --scene synth --blobs 1000 --tris-per-blob 1000 --w 1920 --h 1080 --frames 64 --bounces 8
 //   kl_bench --scene synth --builder gpu ...         (tree built on the GPU instead of the host cores)
 //   kl_bench --scene builtin --interactive-demo      (drives the GLSL_Renderer-shaped host class)
+//   kl_bench --scene synth --gpus 8 --partition tiles --w 3840 --h 2160 --frames 256 --bounces 8      (BASELINE configs[3])
+//   kl_bench --scene synth --gpus 8 --partition samples --blobs 9990 --spheres 10000 --w 3840 --h 2160 --frames 1024 --bounces 8
+//       several GPUs from this one process (kl_group_*): image tiles + RCCL all-gather, or sample ranges + RCCL all-reduce;
+//       --exchange copy replaces RCCL by device copies and lets --devices name one GPU several times (rehearsal)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +25,8 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 #define CK(call) do { kl_status s_ = (call); if (s_ != KL_OK) { std::fprintf(stderr, "%s: %s (%s)\n", #call, kl_status_string(s_), ctx ? kl_last_error(ctx) : ""); return 1; } } while (0)
 
 int main(int argc, char **argv) {
-    std::string scene = "builtin", mode = "pt", out, hdri, albedo, albedo_raw, builder = "host";
+    std::string scene = "builtin", mode = "pt", out, hdri, albedo, albedo_raw, builder = "host", partition = "tiles", exchange = "rccl", devlist;
+    uint32_t gpus = 0, band_rows = 8;
     int araw[3] = {0, 0, 0};
     uint32_t w = 1920, h = 1080, frames = 16, bounces = 0, blobs = 1000, tpb = 1000, spheres = 0, warmup = 1, device = 0, fif = 0;
     bool demo = false;
@@ -37,6 +42,8 @@ int main(int argc, char **argv) {
         else if (a == "--out") out = next(); else if (a == "--hdri") hdri = next(); else if (a == "--albedo") albedo = next();
         else if (a == "--albedo-raw") { albedo_raw = next(); for (int k = 0; k < 3; k++) araw[k] = std::atoi(next()); }
         else if (a == "--builder") builder = next();
+        else if (a == "--gpus") gpus = std::atoi(next()); else if (a == "--partition") partition = next();
+        else if (a == "--exchange") exchange = next(); else if (a == "--devices") devlist = next(); else if (a == "--band-rows") band_rows = std::atoi(next());
         else if (a == "--interactive-demo") demo = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -52,6 +59,60 @@ int main(int argc, char **argv) {
         if (!r.f_run(2)) { std::fprintf(stderr, "%s\n", r.error.c_str()); return 1; }
         std::printf("{\"iFrame\": %zu, \"mode\": %d, \"camera_x\": %.3f}\n", r.iFrame, (int)r.render_mode, r.camera.position.x);
         if (!out.empty() && !r.f_save_png(out)) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+        return 0;
+    }
+    if (gpus > 0) {
+        // one process, `gpus` contexts: scene and textures to every member, frames split by tiles or sample ranges, one exchange
+        std::vector<int32_t> devs;
+        if (!devlist.empty()) { for (size_t p0 = 0; p0 < devlist.size();) { devs.push_back(std::atoi(devlist.c_str() + p0)); size_t c = devlist.find(',', p0); if (c == std::string::npos) break; p0 = c + 1; } }
+        else for (uint32_t k = 0; k < gpus; k++) devs.push_back((int32_t)k);
+        gpus = (uint32_t)devs.size();
+        kl_ctx *ctx = nullptr;        // (CK prints a context's error text; group errors are printed below)
+        kl_group *g = nullptr;
+        const uint32_t split = (partition == "samples" ? KL_SPLIT_SAMPLES : KL_SPLIT_TILES) | (exchange == "copy" ? KL_EXCHANGE_COPY : 0u);
+        CK(kl_group_create(&g, devs.data(), gpus, split, w, h, band_rows));
+#define GK(call) do { kl_status s_ = (call); if (s_ != KL_OK) { std::fprintf(stderr, "%s: %s (%s)\n", #call, kl_status_string(s_), kl_group_last_error(g)); return 1; } } while (0)
+        kl_params p; kl_default_params(&p);
+        p.max_frames = 0; if (bounces) p.max_bounces = bounces; p.frames_in_flight = fif;
+        p.bvh_builder = builder == "gpu" ? KL_BUILD_GPU_LBVH : KL_BUILD_HOST_SAH;
+        GK(kl_group_set_params(g, &p));
+        if (scene == "builtin") GK(kl_group_load_builtin_scene(g));
+        else {
+            kl_synth_params sp = {blobs, tpb, spheres, 1};
+            uint32_t ns, nq, nt, nm;
+            CK(kl_synth_scene_counts(&sp, &ns, &nq, &nt, &nm));
+            std::vector<kl_sphere> s(ns); std::vector<kl_quad> q(nq); std::vector<kl_tri> t(nt); std::vector<kl_material> m(nm);
+            CK(kl_synth_scene_fill(&sp, s.data(), q.data(), t.data(), m.data()));
+            GK(kl_group_upload_scene(g, s.data(), ns, q.data(), nq, t.data(), nt, m.data(), nm));
+        }
+        Image img;
+        if (!hdri.empty()) { if (!img.f_load(hdri)) { std::fprintf(stderr, "cannot read %s\n", hdri.c_str()); return 1; } GK(kl_group_upload_texture(g, KL_TEX_HDRI, img.data.data(), img.width, img.height, img.channels)); }
+        if (!albedo.empty()) { if (!img.f_load(albedo)) { std::fprintf(stderr, "cannot read %s\n", albedo.c_str()); return 1; } GK(kl_group_upload_texture(g, KL_TEX_ALBEDO, img.data.data(), img.width, img.height, img.channels)); }
+        GK(kl_group_set_mode(g, mode == "ao" ? KL_MODE_AO : (mode == "z" ? KL_MODE_Z : KL_MODE_PT)));
+        std::vector<float> image((size_t)w * h * 4);
+        for (uint32_t i = 0; i < warmup; i++) { GK(kl_group_reset(g)); GK(kl_group_render_frames(g, frames, 0)); GK(kl_group_gather(g, nullptr, 0)); }
+        GK(kl_group_reset(g));
+        double t0 = now_s();
+        GK(kl_group_render_frames(g, frames, 0));
+        GK(kl_group_gather(g, nullptr, 0));          // the exchange is inside the timed region; the copy to the host is not
+        double dt = now_s() - t0;
+        GK(kl_group_gather(g, image.data(), image.size() * sizeof(float)));
+        uint64_t rays = 0, paths = 0;
+        for (uint32_t k = 0; k < gpus; k++) { kl_ctx *mc = nullptr; kl_counters cn; GK(kl_group_member(g, k, &mc)); CK(kl_get_counters(mc, &cn)); rays += cn.rays; paths += cn.paths; }
+        double sum = 0.0; for (size_t i = 0; i < image.size(); i += 4) sum += image[i] + image[i + 1] + image[i + 2];
+        std::printf("{\"scene\": \"%s\", \"gpus\": %u, \"partition\": \"%s\", \"exchange\": \"%s\", \"w\": %u, \"h\": %u, \"frames\": %u, \"seconds\": %.6f, "
+                    "\"samples_per_s\": %.1f, \"mrays_per_s\": %.2f, \"image_mean\": %.9g}\n", scene.c_str(), gpus, partition.c_str(), exchange.c_str(), w, h, frames, dt,
+                    (double)w * h * frames / dt, (double)rays / (warmup + 1.0) / dt / 1e6, sum / (3.0 * w * h));
+        (void)paths;
+        if (!out.empty()) {
+            Image o; o.width = (int)w; o.height = (int)h; o.channels = 4; o.data.resize((size_t)w * h * 4);
+            for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w * 4; x++) {
+                float v = image[(size_t)y * w * 4 + x]; v = !(v >= 0.0f) ? 0.0f : (v > 1.0f ? 1.0f : v);
+                o.data[(size_t)(h - 1 - y) * w * 4 + x] = (uint8_t)(v * 255.0f + 0.5f);
+            }
+            if (!o.f_save_png(out)) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+        }
+        kl_group_destroy(g);
         return 0;
     }
     kl_ctx *ctx = nullptr;

@@ -25,6 +25,7 @@ BUILD_HOST_SAH, BUILD_GPU_LBVH = 0, 1
 CONTINUE = 0xFFFFFFFF
 MISS = 0xFFFFFFFF
 NOALLOC_MAX_RAYS = 262144
+SPLIT_TILES, SPLIT_SAMPLES, EXCHANGE_COPY = 0, 1, 0x100
 
 material_dtype = np.dtype([("type", "<i4"), ("color", "<f4", 3), ("emissive", "<f4"),
                            ("roughness", "<f4"), ("ior", "<f4"), ("pad", "<f4")])
@@ -115,6 +116,21 @@ SIGNATURES = {
     "kl_free": (None, [_P]),
     "kl_checkpoint_save": (C.c_int32, [_P, C.c_char_p]),
     "kl_checkpoint_load": (C.c_int32, [_P, C.c_char_p]),
+    "kl_group_create": (C.c_int32, [C.POINTER(_P), C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "kl_group_destroy": (C.c_int32, [_P]),
+    "kl_group_size": (C.c_int32, [_P, C.POINTER(C.c_uint32)]),
+    "kl_group_member": (C.c_int32, [_P, C.c_uint32, C.POINTER(_P)]),
+    "kl_group_upload_scene": (C.c_int32, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32]),
+    "kl_group_load_builtin_scene": (C.c_int32, [_P]),
+    "kl_group_upload_texture": (C.c_int32, [_P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "kl_group_set_params": (C.c_int32, [_P, C.POINTER(Params)]),
+    "kl_group_set_camera": (C.c_int32, [_P, C.POINTER(Camera)]),
+    "kl_group_set_mode": (C.c_int32, [_P, C.c_uint32]),
+    "kl_group_reset": (C.c_int32, [_P]),
+    "kl_group_render_frames": (C.c_int32, [_P, C.c_uint32, C.c_uint32]),
+    "kl_group_gather": (C.c_int32, [_P, _P, C.c_size_t]),
+    "kl_group_image_device": (C.c_int32, [_P, C.c_uint32, C.POINTER(_P)]),
+    "kl_group_last_error": (C.c_char_p, [_P]),
     "kl_status_string": (C.c_char_p, [C.c_int32]),
     "kl_last_error": (C.c_char_p, [_P]),
     "kl_abi_version": (C.c_uint32, []),
@@ -377,3 +393,73 @@ class Renderer:
 
     def copy_accum_from_device(self, device_ptr, nbytes):
         self._ck(lib().kl_copy_accum_from_device(self._h, C.c_void_p(device_ptr), nbytes), "kl_copy_accum_from_device")
+
+
+class Group:
+    """Several GPUs from one process (kl_group_*): one context per device, image tiles or sample ranges, the exchange over
+    RCCL (or, with EXCHANGE_COPY, by device copies: members may then share a GPU)."""
+
+    def __init__(self, devices, split, width, height, band_rows=8):
+        self._h = _P()
+        devs = (C.c_int32 * len(devices))(*devices)
+        rc = lib().kl_group_create(C.byref(self._h), devs, len(devices), split, width, height, band_rows)
+        if rc != 0:
+            raise KlError("kl_group_create failed: %s" % lib().kl_status_string(rc).decode())
+        self.width, self.height, self.n = width, height, len(devices)
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise KlError("%s: %s (%s)" % (what, lib().kl_status_string(rc).decode(), (lib().kl_group_last_error(self._h) or b"").decode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().kl_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_scene(self, spheres=None, quads=None, tris=None, materials=None):
+        def arr(a, dt):
+            return np.ascontiguousarray(a, dtype=dt) if a is not None else np.zeros(0, dtype=dt)
+        s, q, t, m = arr(spheres, sphere_dtype), arr(quads, quad_dtype), arr(tris, tri_dtype), arr(materials, material_dtype)
+        self._ck(lib().kl_group_upload_scene(self._h, _ptr(s), len(s), _ptr(q), len(q), _ptr(t), len(t), _ptr(m), len(m)), "kl_group_upload_scene")
+
+    def load_builtin_scene(self):
+        self._ck(lib().kl_group_load_builtin_scene(self._h), "kl_group_load_builtin_scene")
+
+    def upload_texture(self, which, pixels):
+        px = np.ascontiguousarray(pixels, dtype=np.uint8)
+        if px.ndim == 2:
+            px = px[:, :, None]
+        h, w, ch = px.shape
+        self._ck(lib().kl_group_upload_texture(self._h, which, _ptr(px), w, h, ch), "kl_group_upload_texture")
+
+    def set_params(self, params):
+        self._ck(lib().kl_group_set_params(self._h, C.byref(params)), "kl_group_set_params")
+
+    def set_camera(self, cam):
+        self._ck(lib().kl_group_set_camera(self._h, C.byref(cam)), "kl_group_set_camera")
+
+    def set_mode(self, mode):
+        self._ck(lib().kl_group_set_mode(self._h, mode), "kl_group_set_mode")
+
+    def reset(self):
+        self._ck(lib().kl_group_reset(self._h), "kl_group_reset")
+
+    def render_frames(self, n, first_frame=CONTINUE):
+        self._ck(lib().kl_group_render_frames(self._h, n, first_frame), "kl_group_render_frames")
+
+    def gather(self, to_host=True):
+        out = np.empty((self.height, self.width, 4), dtype=np.float32) if to_host else None
+        self._ck(lib().kl_group_gather(self._h, _ptr(out) if to_host else None, out.nbytes if to_host else 0), "kl_group_gather")
+        return out

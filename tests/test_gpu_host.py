@@ -41,3 +41,23 @@ def test_host_session_follows_the_reference_reset_rules():
     # V switches PATHTRACED -> ZBUFFER and zeroes iFrame; a frame with D held moves the camera by the
     # move sensitivity (0.15) and restarts again (that frame is iFrame 0); two more frames follow
     assert second["mode"] == 2 and second["iFrame"] == 3 and abs(second["camera_x"] - 0.15) < 1e-9
+
+
+def test_kl_bench_drives_a_group_of_gpus(tmp_path):
+    """the headless tool with --gpus: one process, kl_group_*, tiles over RCCL with the one GPU of the box, and three members
+    sharing it through the copy exchange; same image mean as the single-context run"""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "path-tracer_amd", "bin", "kl_bench")
+    base = [exe, "--scene", "builtin", "--w", "96", "--h", "50", "--frames", "5", "--warmup", "0"]
+
+    def run(extra):
+        out = subprocess.run(base + extra, check=True, stdout=subprocess.PIPE, text=True, timeout=120).stdout
+        return json.loads(out.strip().splitlines()[-1])
+
+    tiles = run(["--gpus", "1", "--partition", "tiles"])
+    copy3 = run(["--gpus", "3", "--devices", "0,0,0", "--partition", "tiles", "--exchange", "copy"])
+    samp3 = run(["--gpus", "3", "--devices", "0,0,0", "--partition", "samples", "--exchange", "copy"])
+    assert tiles["gpus"] == 1 and copy3["gpus"] == 3
+    assert tiles["image_mean"] == copy3["image_mean"]                      # tiles: bit-identical images
+    assert abs(samp3["image_mean"] - tiles["image_mean"]) <= 1e-5 * tiles["image_mean"]

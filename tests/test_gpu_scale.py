@@ -128,3 +128,40 @@ def test_ten_million_primitive_mixed_scene(textures):
         raw = r.read_raw()
         cn = r.counters()
     assert np.isfinite(raw).all() and raw[..., :3].max() > 0 and cn.paths == 3840 * 2160
+
+
+def test_dist_partitions_through_rccl_with_one_rank(textures):
+    """klrender/dist.py on the HIP path through the real collectives: torch.distributed "nccl" (= RCCL) with the one rank a
+    one-GPU box allows. Image tiles: all_gather_into_tensor + index un-tile, bit-identical to the plain render; sample ranges:
+    all_reduce(sum) + divide, the plain mean up to fp32 re-association; both twice in a row with reused buffers."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from klrender import dist as kdist
+    scene = kl.synth_scene(blobs=12, tris_per_blob=200, analytic_spheres=10, seed=5)
+    w, h, n = 96, 54, 6
+    port = 29600 + os.getpid() % 1000
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        with kl.Renderer(w, h) as r:
+            _setup(r, scene, textures)
+            r.render_frames(n)
+            mean = r.read_accum()
+            tg = kdist.TileGather(h, w, 8, torch.device("cuda", 0))
+            for _ in range(2):
+                img = kdist.render_tiles(r, n, 8, gatherer=tg).cpu().numpy()
+                assert_bitexact(img, mean, "tiles through RCCL")
+            r.set_shard(0, 1, 1)
+            out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+            for _ in range(2):
+                got = kdist.render_sample_ranges(r, n, out=out).cpu().numpy()
+                assert np.allclose(got[..., :3], mean[..., :3], rtol=2e-5, atol=1e-6) and np.all(got[..., 3] == 1.0)
+            # SAMPLES = 4: the frames past the freeze add nothing, the divisor is the four live frames
+            r.update_params(max_frames=4)
+            r.set_accum_mode(kl.ACCUM_MEAN)
+            r.render_frames(n, first_frame=0)
+            frozen = r.read_accum()
+            got = kdist.render_sample_ranges(r, n, out=out).cpu().numpy()
+            assert np.allclose(got[..., :3], frozen[..., :3], rtol=2e-5, atol=1e-6)
+    finally:
+        dist.destroy_process_group()

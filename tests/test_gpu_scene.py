@@ -335,3 +335,51 @@ def test_trace_rays_tie_between_a_flat_quad_and_a_tree_quad_keeps_the_uv():
         t_ref, p_ref, uv_ref = r.trace_rays(o, d)
     assert (p_ref == 0).all() and np.array_equal(p_bvh, p_ref) and np.array_equal(t_bvh, t_ref)
     assert np.array_equal(uv_bvh, uv_ref) and uv_ref.any()
+
+
+@pytest.mark.parametrize("exchange", ["rccl", "copy"])
+def test_group_partitions_through_the_c_abi(exchange, small_scene, textures):
+    """kl_group_*: image tiles stitch to the one-GPU image bit for bit, sample ranges add up to the mean (fp32
+    re-association only; bit for bit the sum of the members' sums over the frame count). `rccl`: the real collectives
+    (ncclAllGather / ncclAllReduce) with the one member a one-GPU box allows; `copy`: three members sharing the GPU
+    through the copy exchange, ragged image height, so the tile and frame-range arithmetic is exercised with N > 1."""
+    s, q, t, m = small_scene
+    w, h, n, band = 72, 50, 7, 8
+    members = [0] if exchange == "rccl" else [0, 0, 0]
+    flag = 0 if exchange == "rccl" else kl.EXCHANGE_COPY
+    params = kl.default_params(max_bounces=6, max_frames=0)
+
+    def setup(x):
+        x.upload_scene(s, q, t, m)
+        x.upload_texture(kl.TEX_HDRI, textures["hdri"]); x.upload_texture(kl.TEX_ALBEDO, textures["albedo"])
+        x.set_params(params)
+
+    with kl.Renderer(w, h) as r:
+        setup(r)
+        r.render_frames(n)
+        mean = r.read_accum()
+        sums = []
+        for k in range(len(members)):
+            lo, hi = n * k // len(members), n * (k + 1) // len(members)
+            r.set_accum_mode(kl.ACCUM_SUM)
+            if hi > lo:
+                r.render_frames(hi - lo, first_frame=lo)
+                sums.append(r.read_accum())
+    with kl.Group(members, kl.SPLIT_TILES | flag, w, h, band) as g:
+        setup(g)
+        g.render_frames(4, first_frame=0)
+        g.render_frames(n - 4)                      # continues at frame 4
+        assert_bitexact(g.gather(), mean, "tiles over %d member(s), %s exchange" % (len(members), exchange))
+        g.reset()
+        g.render_frames(n, first_frame=0)
+        assert_bitexact(g.gather(), mean, "tiles again after a reset")
+    with kl.Group(members, kl.SPLIT_SAMPLES | flag, w, h, band) as g:
+        setup(g)
+        g.render_frames(n, first_frame=0)
+        got = g.gather()
+    total = sums[0][..., :3].copy()
+    for x in sums[1:]:
+        total += x[..., :3]
+    assert_bitexact(got[..., :3], total / np.float32(n), "sample ranges: sum of the members' sums / frames")
+    assert np.all(got[..., 3] == 1.0)
+    assert np.allclose(got[..., :3], mean[..., :3], rtol=2e-5, atol=1e-6)

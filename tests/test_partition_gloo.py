@@ -34,6 +34,29 @@ def test_frame_ranges_cover():
         assert got == list(range(first, first + n))
 
 
+def test_untile_index_is_the_inverse_of_the_row_band_layout():
+    """the one-gather un-tile (klrender/dist.py TileGather, and the k_untile kernel of kl_group_gather, which computes the same
+    expression per pixel): row y of the image sits at row untile_index[y] of the all-gathered, padded per-rank blocks"""
+    rng = np.random.default_rng(3)
+    for height, world, band in ((54, 2, 8), (33, 3, 5), (50, 3, 8), (36, 8, 4), (10, 4, 16), (2160, 8, 8), (7, 8, 1)):
+        full = rng.random((height, 3, 4), dtype=np.float32)
+        pad = partition.max_local_rows(height, world, band)
+        gathered = np.zeros((world * pad, 3, 4), dtype=np.float32)
+        for r in range(world):
+            rows = partition.rows_of_rank(height, r, world, band)
+            gathered[r * pad:r * pad + len(rows)] = full[rows]
+        idx = partition.untile_index(height, world, band)
+        assert np.array_equal(gathered[idx], full)
+        parts = [gathered[r * pad:(r + 1) * pad] for r in range(world)]
+        assert np.array_equal(partition.stitch(parts, height, world, band), full)
+
+
+def test_live_frames_counts_the_frames_before_the_freeze():
+    from klrender import dist as kdist
+    assert kdist.live_frames(0, 64, 0) == 64 and kdist.live_frames(0, 64, 30) == 30
+    assert kdist.live_frames(20, 20, 30) == 10 and kdist.live_frames(40, 8, 30) == 0
+
+
 def _worker(rank, world, port, height, width, band_rows, n_frames, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
