@@ -136,7 +136,9 @@ __host__ __device__ inline void fastdiv_make(uint32_t d, uint32_t out[2]) {
     out[0] = (uint32_t)((((unsigned long long)1 << (32 + s)) / d) + 1ull - (1ull << 32));
     out[1] = s;
 }
+#if defined(__HIPCC__)
 __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const uint32_t ms[2]) { return (__umulhi(n, ms[0]) + n) >> ms[1]; }
+#endif
 
 // ---- wavefront queues -------------------------------------------------------------
 // One ray = 48 bytes over three arrays so that every access is a full-width vector access:

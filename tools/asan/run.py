@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Feeds build/asan/host_check (AddressSanitizer + UBSan build of the mesh loaders, the SAH builder, the collapse and the scene
+generators) well-formed, truncated and garbage OBJ / PLY files, and the oracle's sanitizer build a small render. CPU only.
+Exit status 0 = no sanitizer report."""
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+EXE = os.path.join(ROOT, "build", "asan", "host_check")
+ORACLE = os.path.join(ROOT, "build", "asan", "oracle_check")
+
+
+def main():
+    rng = np.random.default_rng(1)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    with tempfile.TemporaryDirectory() as d:
+        files = []
+
+        def put(name, data):
+            p = os.path.join(d, name)
+            with open(p, "wb") as f:
+                f.write(data)
+            files.append(p)
+
+        obj = b"v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3 4/4\nf -4 -3 -2\nusemtl b\nf 1//1 2//1 3//1\n"
+        put("good.obj", obj)
+        for k in range(0, len(obj), 7):
+            put("trunc%d.obj" % k, obj[:k])
+        put("badidx.obj", b"v 0 0 0\nf 1 2 3\n")
+        put("hugeidx.obj", b"v 0 0 0\nv 1 1 1\nv 2 2 2\nf 99999999999999999999 2 3\nf 1/9 2 3\nf 1 2\n")
+        head = b"ply\nformat binary_little_endian 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\nproperty float s\nproperty float t\n" \
+               b"element face 2\nproperty list uchar int vertex_indices\nend_header\n"
+        body = b"".join(struct.pack("<5f", *v) for v in ((0, 0, 0, 0, 0), (1, 0, 0, 1, 0), (1, 1, 0, 1, 1), (0, 1, 0, 0, 1))) + \
+            struct.pack("<B4i", 4, 0, 1, 2, 3) + struct.pack("<B3i", 3, 0, 2, 3)
+        put("good.ply", head + body)
+        for k in range(0, len(body), 5):
+            put("trunc%d.ply" % k, head + body[:k])
+        put("neg.ply", head + body[:-12] + struct.pack("<3i", 0, -2, 3))
+        put("count.ply", head.replace(b"vertex 4", b"vertex 4000000000") + body)
+        put("noprops.ply", b"ply\nformat ascii 1.0\nelement vertex 1000000000000\nend_header\n")
+        put("ascii.ply", b"ply\nformat ascii 1.0\nelement vertex 3\nproperty double x\nproperty double y\nproperty double z\nelement face 1\n"
+                         b"property list uchar uint vertex_index\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+        put("biglist.ply", head.replace(b"face 2", b"face 1") + body[:80] + struct.pack("<B", 255) + rng.bytes(40))
+        for k in range(40):
+            put("g%d.ply" % k, head + rng.bytes(int(rng.integers(0, 300))))
+            put("g%d.obj" % k, obj[:int(rng.integers(0, len(obj)))] + rng.bytes(int(rng.integers(0, 200))))
+        put("empty.obj", b"")
+        put("empty.ply", b"")
+        put("unknown.xyz", b"abc")
+        res = subprocess.run([EXE] + files, env=env, capture_output=True, text=True)
+        print(res.stdout.strip())
+        if res.returncode != 0 or "ERROR: AddressSanitizer" in res.stderr or "runtime error" in res.stderr:
+            print(res.stderr[-4000:])
+            return 1
+    if os.path.exists(ORACLE):
+        res = subprocess.run([ORACLE], env=env, capture_output=True, text=True)
+        print(res.stdout.strip())
+        if res.returncode != 0 or "ERROR: AddressSanitizer" in res.stderr or "runtime error" in res.stderr:
+            print(res.stderr[-4000:])
+            return 1
+    print("sanitizer run clean")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
