@@ -50,7 +50,12 @@ enum { KL_TEX_HDRI = 0, KL_TEX_ALBEDO = 1 };
 /* present pass: PostProcess.glsl:38 (CLAMP) or its overwritten lines 19-37 (ACES) */
 enum { KL_TONEMAP_CLAMP = 0, KL_TONEMAP_ACES = 1 };
 /* accumulation: running mean of Accumulation.glsl:16-24, or a plain sum for sample-range sharding */
-enum { KL_ACCUM_MEAN = 0, KL_ACCUM_SUM = 1 };
+enum { KL_ACCUM_MEAN = 0, KL_ACCUM_SUM = 1,
+       /* the running mean exactly as the shipped application stores it: its colour attachments are unsized GL_RGBA
+        * (source/Rendering/Opengl/FBT.cpp:6,21), i.e. RGBA8, so the raw frame and the mean are clamped to [0,1] and rounded
+        * to 8 bits every frame. KL_ACCUM_MEAN keeps the shader's float values (the parity target); this mode reproduces what
+        * the application shows on screen. */
+       KL_ACCUM_MEAN_UNORM8 = 2 };
 /* intersection back end: brute force in declaration order (what RawFrame.glsl:294-328 does) or the SAH BVH */
 enum { KL_ACCEL_AUTO = 0, KL_ACCEL_BRUTE = 1, KL_ACCEL_BVH = 2 };
 /* who builds the tree at kl_upload_scene (no reference counterpart: the reference has no acceleration structure):

@@ -782,6 +782,26 @@ void ko_accumulate(float *acc, const float *raw, size_t npix, uint32_t frame, in
     }
 }
 
+/* Accumulation.glsl:16-24 through the colour attachments the application really creates: unsized GL_RGBA
+ * (source/Rendering/Opengl/FBT.cpp:6,21), which llvmpipe makes RGBA8. Every frame the raw colour is clamped to [0,1] and
+ * rounded to 8 bits when it is written, read back as byte * (1/255), and the running mean is rounded the same way when it is
+ * written. Rounding found by matching the reference run bit for bit: rint(x * 255) in fp32 (ties to even); NaN writes 0. */
+static float unorm8(float x) {
+    x = !(x >= 0.0f) ? 0.0f : (x > 1.0f ? 1.0f : x);
+    return rintf(x * 255.0f) * (1.0f / 255.0f);
+}
+void ko_accumulate_unorm8(float *acc, const float *raw, size_t npix, uint32_t frame, int camera_change) {
+    float weight = (float)frame;
+    for (size_t i = 0; i < npix; i++) {
+        for (int k = 0; k < 3; k++) {
+            float r = unorm8(raw[4 * i + k]);
+            if (frame <= 1 || !camera_change) acc[4 * i + k] = unorm8((acc[4 * i + k] * weight + r) / (weight + 1.0f));
+            else acc[4 * i + k] = r;
+        }
+        acc[4 * i + 3] = 1.0f;
+    }
+}
+
 /* PostProcess.glsl:34-39. CLAMP is the value that line 38 hands to an 8-bit
  * UNORM backbuffer; ACES evaluates the overwritten lines 35-37. */
 void ko_resolve(const float *acc, uint8_t *rgba8, size_t npix, int tonemap) {

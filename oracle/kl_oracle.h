@@ -72,6 +72,8 @@ int ko_render_raw(const ko_scene *s, const ko_camera *cam, const ko_params *p, u
                   ko_counters *counters, int nthreads);
 /* Accumulation.glsl:16-24 */
 void ko_accumulate(float *acc, const float *raw, size_t npix, uint32_t frame, int camera_change);
+/* the same through RGBA8 attachments, as the application ships (FBT.cpp:6,21): raw and mean rounded to 8 bits every frame */
+void ko_accumulate_unorm8(float *acc, const float *raw, size_t npix, uint32_t frame, int camera_change);
 /* PostProcess.glsl:34-39 (CLAMP = what reaches the screen; ACES = the dead-code curve :19-37) */
 void ko_resolve(const float *acc, uint8_t *rgba8, size_t npix, int tonemap);
 

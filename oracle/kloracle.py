@@ -59,6 +59,7 @@ def lib():
         L.ko_render_raw.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
         L.ko_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int]
+        L.ko_accumulate_unorm8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int]
         L.ko_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.ko_rand4.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float * 4)]
         L.ko_hash.argtypes = [C.POINTER(C.c_uint32 * 4), C.POINTER(C.c_uint32 * 4)]
@@ -160,18 +161,20 @@ class Scene:
             pass
 
 
-def accumulate(acc, raw, frame, camera_change=False):
+def accumulate(acc, raw, frame, camera_change=False, unorm8=False):
     assert acc.dtype == np.float32 and raw.dtype == np.float32 and acc.flags.c_contiguous and raw.flags.c_contiguous
-    lib().ko_accumulate(_ptr(acc), _ptr(raw), acc.size // 4, frame, int(camera_change))
+    fn = lib().ko_accumulate_unorm8 if unorm8 else lib().ko_accumulate
+    fn(_ptr(acc), _ptr(raw), acc.size // 4, frame, int(camera_change))
     return acc
 
 
-def render_mean(scene, cam, params, nframes, first_frame=0, nthreads=None, counters=None):
-    """Reference frame loop: raw -> running mean, frames first_frame..first_frame+nframes-1."""
+def render_mean(scene, cam, params, nframes, first_frame=0, nthreads=None, counters=None, unorm8=False):
+    """Reference frame loop: raw -> running mean, frames first_frame..first_frame+nframes-1. unorm8: through RGBA8
+    attachments, as the application ships (raw frame and mean rounded to 8 bits every frame)."""
     acc = np.zeros((params.height, params.width, 4), dtype=np.float32)
     for f in range(first_frame, first_frame + nframes):
         raw = scene.render_raw(cam, params, f, last_acc=acc, nthreads=nthreads, counters=counters)
-        accumulate(acc, raw, f, camera_change=(f == 0))
+        accumulate(acc, raw, f, camera_change=(f == 0), unorm8=unorm8)
     return acc
 
 

@@ -120,11 +120,13 @@ static GLuint link_program(GLuint vs, GLuint fs, const char *name) {
     return p;
 }
 
+static int g_shipped_targets = 0;   /* --shipped-targets: unsized GL_RGBA attachments exactly as FBT.cpp:6 creates them (RGBA8 on llvmpipe) */
+
 static GLuint make_f32_target(int w, int h, GLuint *fbo) {
     GLuint tex;
     glGenTextures(1, &tex);
     glBindTexture(GL_TEXTURE_2D, tex);
-    glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA32F, w, h, 0, GL_RGBA, GL_FLOAT, NULL);
+    glTexImage2D(GL_TEXTURE_2D, 0, g_shipped_targets ? GL_RGBA : GL_RGBA32F, w, h, 0, GL_RGBA, GL_FLOAT, NULL);
     /* NEAREST instead of the reference's LINEAR (FBT.cpp:8-9): the accumulation
        pass samples at exact texel centres, so the filter does not change values. */
     glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
@@ -193,6 +195,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--samples")) samples = atoi(NEXT);
         else if (!strcmp(a, "--spp")) spp = atoi(NEXT);
         else if (!strcmp(a, "--timing")) timing = 1;
+        else if (!strcmp(a, "--shipped-targets")) g_shipped_targets = 1;
         else if (!strcmp(a, "--out-raw")) out_raw = NEXT;
         else if (!strcmp(a, "--out-acc")) out_acc = NEXT;
         else if (!strcmp(a, "--hdri")) { hdri_path = NEXT; hdri_w = atoi(NEXT); hdri_h = atoi(NEXT); hdri_c = atoi(NEXT); }

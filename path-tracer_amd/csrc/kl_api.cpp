@@ -1047,7 +1047,7 @@ kl_status kl_set_shard(kl_ctx *c, uint32_t rank, uint32_t world, uint32_t band_r
 }
 kl_status kl_get_local_rows(kl_ctx *c, uint32_t *rows) { if (!c || !rows) return KL_E_INVALID; *rows = c->local_rows; return KL_OK; }
 kl_status kl_set_accum_mode(kl_ctx *c, uint32_t mode) {
-    if (!c || mode > KL_ACCUM_SUM) return fail(c, KL_E_INVALID, "bad accumulation mode");
+    if (!c || mode > KL_ACCUM_MEAN_UNORM8) return fail(c, KL_E_INVALID, "bad accumulation mode");
     c->accum_mode = mode;
     return kl_reset(c);
 }
@@ -1119,7 +1119,7 @@ static kl_status kl_checkpoint_load_body(kl_ctx *c, const char *path) {
         hd.band_rows != c->band_rows || hd.local_rows != c->local_rows || hd.texels != c->npl) {
         std::fclose(fp); return fail(c, KL_E_STATE, "checkpoint was written for another image size or shard");
     }
-    if (hd.mode > KL_MODE_Z || hd.accum_mode > KL_ACCUM_SUM) { std::fclose(fp); return fail(c, KL_E_INVALID, "corrupt checkpoint header"); }
+    if (hd.mode > KL_MODE_Z || hd.accum_mode > KL_ACCUM_MEAN_UNORM8) { std::fclose(fp); return fail(c, KL_E_INVALID, "corrupt checkpoint header"); }
     std::vector<float4> acc(c->npl), raw(c->npl);
     bool ok = std::fread(acc.data(), sizeof(float4), acc.size(), fp) == acc.size() &&
               std::fread(raw.data(), sizeof(float4), raw.size(), fp) == raw.size();

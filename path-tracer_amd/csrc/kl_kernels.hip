@@ -882,6 +882,13 @@ __global__ __launch_bounds__(256) void k_compact(FrameDev f, RayQueue qin, const
     }
 }
 
+// what an RGBA8 colour attachment keeps of a value: clamp to [0,1], round to nearest (ties to even) on the 8-bit grid, read
+// back as byte * (1/255); NaN stores 0 (llvmpipe's conversion, matched bit for bit against the reference run)
+__device__ __forceinline__ float unorm8(float x) {
+    x = !(x >= 0.0f) ? 0.0f : (x > 1.0f ? 1.0f : x);
+    return rintf(x * 255.0f) * (1.0f / 255.0f);
+}
+
 // ------------------------------------------------------------------ accumulate
 // resources/Shaders/Accumulation.glsl:16-24 applied to the frames of the batch in order.
 // A frame at or past max_frames contributes the accumulation texel itself (RF:426,461-463).
@@ -910,6 +917,14 @@ __global__ __launch_bounds__(256) void k_accumulate(FrameDev f, const float4 *ra
                 // a frozen frame leaves the mean where it is, i.e. adds no term to the sum
                 if (!frozen) { a.x += r.x; a.y += r.y; a.z += r.z; }
                 a.w = 1.0f;
+            } else if (accum_mode == KL_ACCUM_MEAN_UNORM8) {
+                // the application's own attachments (unsized GL_RGBA = RGBA8, FBT.cpp:6,21): the raw colour and the mean are
+                // clamped and rounded to 8 bits whenever they are written
+                r = make_float4(unorm8(r.x), unorm8(r.y), unorm8(r.z), 1.0f);
+                if (frame <= 1u || !(camera_change && s == 0u)) {
+                    const float w = (float)frame;
+                    a = make_float4(unorm8((a.x * w + r.x) / (w + 1.0f)), unorm8((a.y * w + r.y) / (w + 1.0f)), unorm8((a.z * w + r.z) / (w + 1.0f)), 1.0f);
+                } else a = r;
             } else if (frame <= 1u || !(camera_change && s == 0u)) {
                 float w = (float)frame;
                 a.x = (a.x * w + r.x) / (w + 1.0f);

@@ -19,7 +19,7 @@ MODE_AO, MODE_PT, MODE_Z = 0, 1, 2
 DIFFUSE, GLASS, EMISSIVE, TEXTURED = 0, 1, 2, 3
 TEX_HDRI, TEX_ALBEDO = 0, 1
 TONEMAP_CLAMP, TONEMAP_ACES = 0, 1
-ACCUM_MEAN, ACCUM_SUM = 0, 1
+ACCUM_MEAN, ACCUM_SUM, ACCUM_MEAN_UNORM8 = 0, 1, 2
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
 BUILD_HOST_SAH, BUILD_GPU_LBVH = 0, 1
 CONTINUE = 0xFFFFFFFF

@@ -41,7 +41,7 @@ POSES = {
 }
 
 
-def run_ref(w, h, mode, first_frame, nframes, textures, bounces=None, samples=None, acc=False, cam=None, spp=None):
+def run_ref(w, h, mode, first_frame, nframes, textures, bounces=None, samples=None, acc=False, cam=None, spp=None, shipped=False):
     raw_path = os.path.join(TMP, "kl_golden_raw.f32")
     acc_path = os.path.join(TMP, "kl_golden_acc.f32")
     cmd = [BIN, "--shaders", os.path.join(REF, "resources", "Shaders"), "--w", str(w), "--h", str(h),
@@ -58,6 +58,8 @@ def run_ref(w, h, mode, first_frame, nframes, textures, bounces=None, samples=No
         cmd += ["--samples", str(samples)]
     if spp is not None:
         cmd += ["--spp", str(spp)]
+    if shipped:
+        cmd += ["--shipped-targets"]
     if cam is not None:
         cmd += ["--cam"] + [repr(float(v)) for part in cam for v in part]
     res = subprocess.run(cmd, check=True, stderr=subprocess.PIPE, text=True)
@@ -92,6 +94,15 @@ def poses(tex, manifest):
     acc, _ = run_ref(64, 36, 1, 0, 4, tex, samples=64, spp=2, acc=True)
     out["default_pt_mean4"] = acc[:, :, :3].copy()
     np.savez_compressed(os.path.join(HERE, "spp2.npz"), **out)
+    # As shipped: the application's colour attachments are unsized GL_RGBA (FBT.cpp:6,21) = RGBA8 on llvmpipe, so the raw
+    # frame AND the running mean are clamped to [0,1] and rounded to 8 bits every frame. 8 frames, path traced and ZDepth.
+    out = {}
+    for mode, mname in ((1, "pt"), (2, "z")):
+        acc, _ = run_ref(64, 36, mode, 0, 8, tex, samples=64, acc=True, shipped=True)
+        out[mname + "_mean8"] = np.rint(acc[:, :, :3] * 255.0).astype(np.uint8)
+        assert np.abs(acc[:, :, :3] * 255.0 - out[mname + "_mean8"]).max() < 1e-3
+    np.savez_compressed(os.path.join(HERE, "shipped_rgba8_64x36_8frames.npz"), **out)
+    manifest["files"]["shipped_rgba8_64x36_8frames.npz"] = {"w": 64, "h": 36, "frames": 8, "targets": "unsized GL_RGBA as FBT.cpp:6 (RGBA8)", "keys": sorted(out)}
     manifest["files"]["spp2.npz"] = {"spp": 2, "declared_patch": "#define SPP 1 -> 2", "keys": sorted(out)}
 
 

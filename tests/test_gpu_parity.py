@@ -289,6 +289,23 @@ def test_spp_grid(textures, oracle_builtin):
         assert_bitexact(r.read_accum(), ko.render_mean(osc, ko.default_camera(), p, 5), "spp 3, triangle scene")
 
 
+def test_accumulation_as_shipped_through_rgba8(textures, oracle_builtin):
+    """KL_ACCUM_MEAN_UNORM8: the running mean kept the way the shipped application keeps it (RGBA8 attachments, FBT.cpp:6,21),
+    across batches and calls; bit for bit the oracle's, and the reference run's bytes within its budget"""
+    from test_oracle_golden import check_shipped_rgba8
+    g = golden("shipped_rgba8_64x36_8frames.npz")
+    for mode, key in ((kl.MODE_PT, "pt_mean8"), (kl.MODE_Z, "z_mean8")):
+        with make_renderer(64, 36, textures, max_frames=0, frames_in_flight=3) as r:
+            r.set_mode(mode)
+            r.set_accum_mode(kl.ACCUM_MEAN_UNORM8)
+            r.render_frames(5)
+            r.render_frames(3)
+            acc = r.read_accum()
+        p = ko.default_params(width=64, height=36, mode=KO_MODE[mode], max_frames=0)
+        assert_bitexact(acc, ko.render_mean(oracle_builtin, ko.default_camera(), p, 8, unorm8=True), "8-bit attachments " + key)
+        check_shipped_rgba8(key, acc[..., :3], g[key])
+
+
 def test_resolve_matches_present_pass(textures):
     with make_renderer(64, 36, textures) as r:
         r.render_frames(2)

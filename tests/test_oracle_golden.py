@@ -186,6 +186,28 @@ def test_spp_grid_two(oracle_builtin):
         check_spp2_image(key, out[..., :3], g[key])
 
 
+def check_shipped_rgba8(key, acc, ref8):
+    """acc: float mean kept through 8-bit attachments (values on the byte grid); ref8: the reference run's bytes"""
+    got8 = np.rint(acc * 255.0).astype(np.int32)
+    assert np.abs(acc * 255.0 - got8).max() < 1e-3, key                      # every value sits on the 8-bit grid
+    same = np.mean(got8 == ref8.astype(np.int32))
+    if key.startswith("z"):
+        assert same == 1.0, key
+    else:
+        assert same >= 0.997 and np.abs(got8 - ref8.astype(np.int32)).max() <= 4, key      # measured 0.9984 (texel flips), max 3
+
+
+def test_accumulation_as_shipped_through_rgba8(oracle_builtin):
+    """The application's attachments are unsized GL_RGBA (FBT.cpp:6,21) = RGBA8: raw frame and running mean are rounded to
+    8 bits every frame. The reference shaders ran with exactly those attachments; only 38 % of that image's bytes equal the
+    float mean rounded once, so the per-frame rounding is what this pins."""
+    g = golden("shipped_rgba8_64x36_8frames.npz")
+    for mode, key in ((ko.MODE_PT, "pt_mean8"), (ko.MODE_Z, "z_mean8")):
+        p = ko.default_params(width=64, height=36, mode=mode, max_frames=0)
+        acc = ko.render_mean(oracle_builtin, ko.default_camera(), p, 8, unorm8=True)[..., :3]
+        check_shipped_rgba8(key, acc, g[key])
+
+
 def test_rng_known_answers():
     """rand4() for seed (x, y, frame, x+y); values observed from the shader on llvmpipe."""
     kat = {
