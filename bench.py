@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
 """Headline benchmark: path samples/s at 1080p, 8 bounces, on N MI355X.
 
-Workload (BASELINE.json configs[2]): the synthetic 1M-triangle textured scene, 1920x1080,
-64 spp, bounce cap 8, path-traced mode. One step = one full pass: 64 frames traced and
-accumulated (132.7 M path samples). Scene, BVH and textures are resident in HBM before the
-timed region. With N > 1 every rank renders its own 64-frame sample range of the same image
-(weak scaling, sample-range partition) and the per-rank sums are added with one RCCL
-all-reduce per step, inside the timed region.
+Workload (BASELINE.json configs[2], `--config 3`): the synthetic 1M-triangle textured scene, 1920x1080, 64 spp, bounce cap 8,
+path-traced mode. One step = one full pass: 64 frames traced and accumulated (132.7 M path samples). Scene, BVH and textures are
+resident in HBM before the timed region, and no per-launch events are recorded inside it. `--config 4` / `--config 5` select
+configs[3] (3840x2160, 256 spp, image tiles) and configs[4] (10 M primitives, 4K, 1024 spp, sample ranges).
+
+N > 1 (one process per GPU, torch.distributed "nccl" = RCCL): `--partition samples` (default): every rank renders its frame
+range of the same image as a sum, one all-reduce + divide per step (`--scaling weak`: spp frames per rank, N*spp in all;
+`--scaling strong`: spp frames in all); `--partition tiles`: every rank renders all frames of its row bands, one all-gather +
+un-tile per step. The exchange is inside the timed region; its buffers are allocated before it.
+
+After the timed region (none of it enters `value`): one single-lane step with HIP events around every kernel launch and one
+with the traversal kernel's own wave-level tallies (the `roofline` speed-of-light model), the library-default pass with camera
+rays shared by a batch's frames (`value_shared_camera_rays`), and the CPU oracle on a bounded sample (`cpu_baseline`).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
