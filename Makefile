@@ -34,13 +34,14 @@ tools: $(LIB)
 oracle:
 	$(MAKE) -C oracle all
 
-# Host-side code that handles caller data, and the oracle, under AddressSanitizer + UBSan (CPU only: g++/gcc, no device code),
-# run over well-formed, truncated and garbage mesh files (tools/asan/run.py).
+# Host-side code that handles caller data (mesh and image loaders, builders), and the oracle, under AddressSanitizer + UBSan (CPU only: g++/gcc, no device code),
+# run over well-formed, truncated and garbage mesh and image files (tools/asan/run.py).
 ASAN_FLAGS := -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined
 asan:
 	@mkdir -p build/asan
 	g++ $(ASAN_FLAGS) -std=c++17 -ffp-contract=off -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -I$(CSRC) -o build/asan/host_check \
 	    tools/asan/host_check.cpp $(CSRC)/kl_mesh_io.cpp $(CSRC)/kl_bvh.cpp $(CSRC)/kl_scene.cpp -lpthread
+	g++ $(ASAN_FLAGS) -std=c++17 -I$(PKG)/host -o build/asan/image_check tools/asan/image_check.cpp $(PKG)/host/kl_image_impl.cpp $(PKG)/host/kl_jpeg_impl.cpp -lz
 	gcc $(ASAN_FLAGS) -std=c11 -Wno-stringop-overread -fopenmp -mfma -ffp-contract=off -Ioracle -o build/asan/oracle_check tools/asan/oracle_check.c oracle/kl_oracle.c -lm
 	python3 tools/asan/run.py
 

@@ -5,6 +5,7 @@
 //   kl_bench --scene synth --blobs 1000 --tris-per-blob 1000 --w 1920 --h 1080 --frames 64 --bounces 8
 //   kl_bench --scene synth --builder gpu ...         (tree built on the GPU instead of the host cores)
 //   kl_bench --scene builtin --interactive-demo      (drives the GLSL_Renderer-shaped host class)
+//   kl_bench --decode in.png out.raw                 (the host's image loader alone: writes the 8-bit pixels, prints "w h channels")
 //   kl_bench --scene synth --gpus 8 --partition tiles --w 3840 --h 2160 --frames 256 --bounces 8      (BASELINE configs[3])
 //   kl_bench --scene synth --gpus 8 --partition samples --blobs 9990 --spheres 10000 --w 3840 --h 2160 --frames 1024 --bounces 8
 //       several GPUs from this one process (kl_group_*): image tiles + RCCL all-gather, or sample ranges + RCCL all-reduce;
@@ -25,7 +26,7 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 #define CK(call) do { kl_status s_ = (call); if (s_ != KL_OK) { std::fprintf(stderr, "%s: %s (%s)\n", #call, kl_status_string(s_), ctx ? kl_last_error(ctx) : ""); return 1; } } while (0)
 
 int main(int argc, char **argv) {
-    std::string scene = "builtin", mode = "pt", out, hdri, albedo, albedo_raw, builder = "host", partition = "tiles", exchange = "rccl", devlist;
+    std::string scene = "builtin", mode = "pt", out, hdri, albedo, albedo_raw, decode_in, decode_out, builder = "host", partition = "tiles", exchange = "rccl", devlist;
     uint32_t gpus = 0, band_rows = 8;
     int araw[3] = {0, 0, 0};
     uint32_t w = 1920, h = 1080, frames = 16, bounces = 0, blobs = 1000, tpb = 1000, spheres = 0, warmup = 1, device = 0, fif = 0;
@@ -45,7 +46,17 @@ int main(int argc, char **argv) {
         else if (a == "--gpus") gpus = std::atoi(next()); else if (a == "--partition") partition = next();
         else if (a == "--exchange") exchange = next(); else if (a == "--devices") devlist = next(); else if (a == "--band-rows") band_rows = std::atoi(next());
         else if (a == "--interactive-demo") demo = true;
+        else if (a == "--decode") { decode_in = next(); decode_out = next(); }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    if (!decode_in.empty()) {
+        Image img;
+        if (!img.f_load(decode_in)) { std::fprintf(stderr, "cannot decode %s\n", decode_in.c_str()); return 1; }
+        FILE *f = std::fopen(decode_out.c_str(), "wb");
+        if (!f || std::fwrite(img.data.data(), 1, img.data.size(), f) != img.data.size()) { std::fprintf(stderr, "cannot write %s\n", decode_out.c_str()); return 1; }
+        std::fclose(f);
+        std::printf("%d %d %d\n", img.width, img.height, img.channels);
+        return 0;
     }
     if (demo) {
         // the reference's session in miniature: accumulate, press V (ZDepth), strafe with D, accumulate again

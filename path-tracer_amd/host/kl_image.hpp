@@ -12,11 +12,15 @@ struct Image {
     std::vector<uint8_t> data;
     int width = 0, height = 0, channels = 0;
 
-    // PNG: 8-bit grey / RGB / RGBA, non-interlaced (what the reference's two textures are). false on failure.
+    // Chosen by the file's first bytes, not its name, as stb_image does ("resources/Texture.png" holds JPEG data).
+    // PNG: 8-bit grey / RGB / RGBA, non-interlaced. JPEG: baseline Huffman, grey or three components. false on failure.
     bool f_load(const std::string &path);
     // raw dump written by the tests: width*height*channels bytes
     bool f_load_raw(const std::string &path, int w, int h, int c);
     bool f_save_png(const std::string &path) const;
 };
+
+// Baseline JPEG bytes -> 8-bit grey or RGB with stb_image's arithmetic (kl_jpeg_impl.cpp). false on failure.
+bool decode_jpeg(const uint8_t *bytes, size_t size, Image &img);
 
 }  // namespace klhost

@@ -1,4 +1,4 @@
-// Minimal PNG codec on top of zlib (inflate/deflate + the five scanline filters).
+// Minimal PNG codec on top of zlib (inflate/deflate + the five scanline filters); JPEG data goes to kl_jpeg_impl.cpp.
 #include "kl_image.hpp"
 
 #include <zlib.h>
@@ -40,7 +40,9 @@ void chunk(std::vector<uint8_t> &png, const char *type, const std::vector<uint8_
 bool Image::f_load(const std::string &path) {
     std::vector<uint8_t> file;
     static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
-    if (!read_file(path, file) || file.size() < 33 || std::memcmp(file.data(), sig, 8) != 0) return false;
+    if (!read_file(path, file)) return false;
+    if (file.size() >= 3 && file[0] == 0xFF && file[1] == 0xD8 && file[2] == 0xFF) return decode_jpeg(file.data(), file.size(), *this);
+    if (file.size() < 33 || std::memcmp(file.data(), sig, 8) != 0) return false;
     std::vector<uint8_t> idat;
     int bit_depth = 0, color = -1, interlace = 0;
     size_t pos = 8;
@@ -61,6 +63,8 @@ bool Image::f_load(const std::string &path) {
     channels = color == 0 ? 1 : (color == 2 ? 3 : (color == 6 ? 4 : 0));
     if (!channels) return false;
     const size_t stride = (size_t)width * channels;
+    // deflate expands by at most 1032:1: a header that announces more pixels than the data can hold is refused before allocating
+    if ((stride + 1) * (size_t)height > idat.size() * 1040 + 1024) return false;
     std::vector<uint8_t> raw((stride + 1) * (size_t)height);
     uLongf raw_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return false;

@@ -106,7 +106,64 @@ def poses(tex, manifest):
     manifest["files"]["spp2.npz"] = {"spp": 2, "declared_patch": "#define SPP 1 -> 2", "keys": sorted(out)}
 
 
+def jpeg_cases():
+    """Small JPEG files written by Pillow (sub-sampling modes, odd sizes, restart intervals, own Huffman tables, grey) with
+    the bytes the reference's vendored stb_image decodes from each (oracle/_ref/stb_decode), and the reference's own JPEG
+    texture copied as a file: known answers for the host's JPEG decoder. Adds jpeg_stb.npz and leaves the other files alone."""
+    import io
+    stb = os.path.join(ROOT, "oracle", "_ref", "stb_decode")
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:97, 0:131]
+    base = np.stack([127 + 120 * np.sin(xx / 9.0) * np.cos(yy / 7.0), 127 + 120 * np.cos(xx / 5.0 + yy / 11.0), (xx * 3 + yy * 5) % 256], axis=-1)
+    base = np.clip(base + rng.normal(0, 12, base.shape), 0, 255).astype(np.uint8)
+    cases = {
+        "s444_37x29": dict(size=(37, 29), subsampling=0, quality=90),
+        "s422_50x33": dict(size=(50, 33), subsampling=1, quality=85),
+        "s420_45x31": dict(size=(45, 31), subsampling=2, quality=80),
+        "s420_131x97_q100": dict(size=(131, 97), subsampling=2, quality=100),
+        "s420_64x48_q5": dict(size=(64, 48), subsampling=2, quality=5),
+        "s420_optimized": dict(size=(70, 41), subsampling=2, quality=75, optimize=True),
+        "s420_restart_rows": dict(size=(83, 52), subsampling=2, quality=75, restart_marker_rows=1),
+        "s444_restart_blocks": dict(size=(61, 35), subsampling=0, quality=75, restart_marker_blocks=3),
+        "s411_57x23": dict(size=(57, 23), subsampling="4:1:1", quality=80),
+        "s440_33x47": dict(size=(33, 47), subsampling="4:4:0", quality=80),
+        "s420_2x2": dict(size=(2, 2), subsampling=2, quality=90),
+        "s420_1x1": dict(size=(1, 1), subsampling=2, quality=90),
+        "s422_2x9": dict(size=(2, 9), subsampling=1, quality=90),
+        "grey_20x17": dict(size=(20, 17), grey=True, quality=85),
+        "grey_restart": dict(size=(40, 24), grey=True, quality=60, restart_marker_blocks=2),
+    }
+    out, made = {}, []
+    for name, c in cases.items():
+        w, h = c.pop("size")
+        grey = c.pop("grey", False)
+        img = Image.fromarray(base[:h, :w, 1] if grey else base[:h, :w])
+        buf = io.BytesIO()
+        try:
+            img.save(buf, "JPEG", **c)
+        except Exception as e:                                     # a mode this Pillow does not write
+            print("skipped", name, e)
+            continue
+        jpg, raw = os.path.join(TMP, "kl_case.jpg"), os.path.join(TMP, "kl_case.raw")
+        open(jpg, "wb").write(buf.getvalue())
+        shape = subprocess.run([stb, jpg, raw], check=True, stdout=subprocess.PIPE, text=True).stdout.split()
+        ww, hh, cc = map(int, shape)
+        assert (ww, hh) == (w, h) and cc == (1 if grey else 3)
+        out[name + "__jpeg"] = np.frombuffer(buf.getvalue(), dtype=np.uint8)
+        out[name + "__stb"] = np.fromfile(raw, dtype=np.uint8).reshape(h, w, cc)
+        made.append(name)
+    np.savez_compressed(os.path.join(HERE, "jpeg_stb.npz"), **out)
+    shutil.copyfile(os.path.join(REF, "resources", "Texture.png"), os.path.join(HERE, "assets", "Texture.png"))
+    manifest = json.load(open(os.path.join(HERE, "MANIFEST.json")))
+    manifest["files"]["jpeg_stb.npz"] = {"cases": made, "encoder": "Pillow %s" % Image.__version__ if hasattr(Image, "__version__") else "Pillow",
+                                         "decoder": "external/stb_image.h of the reference through oracle/stb_decode.c"}
+    json.dump(manifest, open(os.path.join(HERE, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
+    print("jpeg_stb.npz:", made)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "jpeg":
+        return jpeg_cases()
     if not os.path.exists(BIN):
         sys.exit("build oracle/_ref/glsl_ref first: make -C oracle ref")
     only_poses = len(sys.argv) > 1 and sys.argv[1] == "poses"     # adds poses.npz / spp2.npz and leaves the other files alone

@@ -17,11 +17,9 @@ BENCH = os.path.join(ROOT, "path-tracer_amd", "bin", "kl_bench")
 def test_kl_bench_renders_the_builtin_scene(tmp_path, oracle_builtin, textures):
     assert os.path.exists(BENCH), "build the host tool first (make tools)"
     out = str(tmp_path / "frame.png")
-    alb = str(tmp_path / "albedo.raw")
-    textures["albedo"].tofile(alb)
     res = subprocess.run([BENCH, "--scene", "builtin", "--mode", "pt", "--w", "64", "--h", "36", "--frames", "3", "--warmup", "0",
                           "--hdri", os.path.join(GOLDEN, "assets", "Background.png"),
-                          "--albedo-raw", alb, "1920", "1080", "3", "--out", out],
+                          "--albedo", os.path.join(GOLDEN, "assets", "Texture.png"), "--out", out],     # JPEG data, as the reference ships it
                          check=True, capture_output=True, text=True, timeout=120)
     info = json.loads(res.stdout.strip().splitlines()[-1])
     assert info["frames"] == 3 and info["samples_per_s"] > 0 and 3 < info["rays_per_sample"] < 9
@@ -30,7 +28,7 @@ def test_kl_bench_renders_the_builtin_scene(tmp_path, oracle_builtin, textures):
     p = ko.default_params(width=64, height=36, mode=ko.MODE_PT, max_frames=0)
     acc = ko.render_mean(oracle_builtin, ko.default_camera(), p, 3)
     want = ko.resolve(acc)[::-1]                 # PNG rows run top to bottom, buffer rows bottom to top
-    assert np.array_equal(got, want)             # exercises the C++ PNG reader (textures) and writer
+    assert np.array_equal(got, want)             # exercises the C++ PNG and JPEG readers (textures) and the PNG writer
 
 
 def test_host_session_follows_the_reference_reset_rules():

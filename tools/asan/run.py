@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Feeds build/asan/host_check (AddressSanitizer + UBSan build of the mesh loaders, the SAH builder, the collapse and the scene
-generators) well-formed, truncated and garbage OBJ / PLY files, and the oracle's sanitizer build a small render. CPU only.
+generators) well-formed, truncated and garbage OBJ / PLY files, build/asan/image_check (the host's PNG and JPEG loaders) whole,
+truncated and damaged images, and the oracle's sanitizer build a small render. CPU only.
 Exit status 0 = no sanitizer report."""
 import os
 import struct
@@ -13,6 +14,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 EXE = os.path.join(ROOT, "build", "asan", "host_check")
 ORACLE = os.path.join(ROOT, "build", "asan", "oracle_check")
+IMAGES = os.path.join(ROOT, "build", "asan", "image_check")
 
 
 def main():
@@ -57,6 +59,50 @@ def main():
         if res.returncode != 0 or "ERROR: AddressSanitizer" in res.stderr or "runtime error" in res.stderr:
             print(res.stderr[-4000:])
             return 1
+    if os.path.exists(IMAGES):
+        with tempfile.TemporaryDirectory() as d:
+            files = []
+
+            def put(name, data):
+                p = os.path.join(d, name)
+                with open(p, "wb") as f:
+                    f.write(data)
+                files.append(p)
+
+            cases = np.load(os.path.join(ROOT, "tests", "golden", "jpeg_stb.npz"))
+            for key in cases.files:
+                if not key.endswith("__jpeg"):
+                    continue
+                jpg = cases[key].tobytes()
+                put(key + ".jpg", jpg)
+                for k in range(0, len(jpg), max(1, len(jpg) // 23)):
+                    put("%s.t%d.jpg" % (key, k), jpg[:k])
+                for k in range(12):                       # a few bytes overwritten anywhere: headers, tables, entropy-coded data
+                    dmg = bytearray(jpg)
+                    for pos in rng.integers(2, len(jpg), size=int(rng.integers(1, 6))):
+                        dmg[int(pos)] = int(rng.integers(0, 256))
+                    put("%s.d%d.jpg" % (key, k), bytes(dmg))
+            put("huge.jpg", bytes.fromhex("ffd8ffc0000b08ffffffff01011100ffda0008010100003f00") + rng.bytes(64))
+            put("soi.jpg", b"\xff\xd8\xff")
+            import zlib
+
+            def png(w, h, color, raw):
+                def chunk(t, b):
+                    return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b))
+                return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, color, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+            rows = b"".join(bytes([y % 5]) + rng.bytes(7 * 3) for y in range(9))
+            good = png(7, 9, 2, rows)
+            put("good.png", good)
+            for k in range(0, len(good), 11):
+                put("t%d.png" % k, good[:k])
+            put("short.png", png(7, 9, 2, rows[:50]))
+            put("wide.png", png(70000, 70000, 6, rows))
+            put("filter.png", png(7, 9, 2, b"".join(bytes([9]) + rng.bytes(21) for _ in range(9))))
+            res = subprocess.run([IMAGES] + files, env=env, capture_output=True, text=True)
+            print(res.stdout.strip())
+            if res.returncode != 0 or "ERROR: AddressSanitizer" in res.stderr or "runtime error" in res.stderr:
+                print(res.stderr[-4000:])
+                return 1
     if os.path.exists(ORACLE):
         res = subprocess.run([ORACLE], env=env, capture_output=True, text=True)
         print(res.stdout.strip())
