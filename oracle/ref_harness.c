@@ -15,7 +15,8 @@
  *   2. --zero-col turns `vec3 col;` (RawFrame.glsl:433,445) into
  *      `vec3 col = vec3(0);`;
  *   3. --bounces / --samples / --spp rewrite the RAY_BOUNCES / SAMPLES / SPP defines
- *      (RawFrame.glsl:36,38);
+ *      (RawFrame.glsl:36-38); --define NAME VALUE rewrites any other one-line
+ *      #define of RawFrame.glsl (HDRI_STRENGTH, AO_LENGTH, MAX_DIST, EPSILON: :32-40);
  *   4. the accumulation pass ping-pongs between two textures instead of
  *      sampling the texture it renders to (GLSL_Renderer.cpp:312-324).
  *
@@ -95,6 +96,22 @@ static char *replace_all(char *src, const char *from, const char *to) {
     int guard = 0;
     while (strstr(src, from) && guard++ < 16) src = replace_once(src, from, to, 1);
     return src;
+}
+
+/* the line `#define NAME <anything>` becomes `#define NAME VALUE` */
+static char *redefine(char *src, const char *name, const char *value) {
+    char key[128];
+    snprintf(key, sizeof key, "#define %s ", name);
+    char *p = strstr(src, key);
+    if (!p || (p != src && p[-1] != '\n')) { fprintf(stderr, "no #define %s in the shader\n", name); exit(2); }
+    char *eol = strchr(p, '\n');
+    size_t n = strlen(src), head = (size_t)(p - src), tail = eol ? (size_t)(eol - src) : n;
+    char *out = malloc(n + strlen(key) + strlen(value) + 2);
+    memcpy(out, src, head);
+    int w = sprintf(out + head, "%s%s", key, value);
+    strcpy(out + head + w, src + tail);
+    free(src);
+    return out;
 }
 
 static GLuint compile(GLenum type, const char *src, const char *name) {
@@ -180,6 +197,7 @@ int main(int argc, char **argv) {
     int mode = 2, first_frame = 0, nframes = 1, zero_col = 0, bounces = -1, samples = -1, spp = -1, timing = 0;
     float cam_pos[3] = {0, 1, 5}, cam_front[3] = {0, 0, -1}, cam_up[3] = {0, 1, 0};
     float focal = 0.05f, sensor = 0.036f;
+    const char *def_name[8], *def_value[8]; int ndefs = 0;
 
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -207,6 +225,7 @@ int main(int argc, char **argv) {
         }
         else if (!strcmp(a, "--focal")) focal = (float)atof(NEXT);
         else if (!strcmp(a, "--sensor")) sensor = (float)atof(NEXT);
+        else if (!strcmp(a, "--define")) { if (ndefs == 8) { fprintf(stderr, "too many --define\n"); return 2; } def_name[ndefs] = NEXT; def_value[ndefs++] = NEXT; }
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }
     setenv("MESA_GL_VERSION_OVERRIDE", "4.6", 0);
@@ -263,6 +282,7 @@ int main(int argc, char **argv) {
         char to[64]; snprintf(to, sizeof to, "#define SAMPLES       %d", samples);
         raw_src = replace_once(raw_src, "#define SAMPLES       30", to, 1);
     }
+    for (int k = 0; k < ndefs; k++) raw_src = redefine(raw_src, def_name[k], def_value[k]);
     GLuint vs = compile(GL_VERTEX_SHADER, vs_src, "Vert");
     GLuint raw_prog = link_program(vs, compile(GL_FRAGMENT_SHADER, raw_src, "RawFrame"), "RawFrame");
     GLuint acc_prog = link_program(vs, compile(GL_FRAGMENT_SHADER, acc_src, "Accumulation"), "Accumulation");

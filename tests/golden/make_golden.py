@@ -41,7 +41,20 @@ POSES = {
 }
 
 
-def run_ref(w, h, mode, first_frame, nframes, textures, bounces=None, samples=None, acc=False, cam=None, spp=None, shipped=False):
+# lens and shader #defines away from their defaults (RawFrame.glsl:32-40; iCameraFocalLength / iCameraSensorWidth,
+# GLSL_Renderer.cpp:293-294). "lens" is the setting of tests/test_gpu_parity.py::test_other_camera_and_params; "near" cuts
+# the scene off at MAX_DIST 4.5 (the back of the box counts as a miss) with a coarse EPSILON and a strong, short AO.
+_front = [float(np.float32(v)) for v in np.array([-0.3, -0.15, -1.0]) / np.linalg.norm([-0.3, -0.15, -1.0])]
+PARAM_CASES = {
+    "lens": dict(cam=((1.2, 1.7, 3.0), tuple(_front), (0, 1, 0)), focal=0.035, sensor=0.03, w=120, h=80, frame=3,
+                 defines={"AO_LENGTH": "0.5", "HDRI_STRENGTH": "1.5", "EPSILON": "0.002", "MAX_DIST": "40.0"}),
+    "near": dict(cam=((0.3, 1.2, 3.5), (0, 0, -1), (0, 1, 0)), focal=0.02, sensor=0.05, w=96, h=54, frame=1,
+                 defines={"AO_LENGTH": "0.25", "HDRI_STRENGTH": "3.0", "EPSILON": "0.01", "MAX_DIST": "4.5"}),
+}
+
+
+def run_ref(w, h, mode, first_frame, nframes, textures, bounces=None, samples=None, acc=False, cam=None, spp=None, shipped=False,
+            focal=None, sensor=None, defines=None):
     raw_path = os.path.join(TMP, "kl_golden_raw.f32")
     acc_path = os.path.join(TMP, "kl_golden_acc.f32")
     cmd = [BIN, "--shaders", os.path.join(REF, "resources", "Shaders"), "--w", str(w), "--h", str(h),
@@ -62,6 +75,12 @@ def run_ref(w, h, mode, first_frame, nframes, textures, bounces=None, samples=No
         cmd += ["--shipped-targets"]
     if cam is not None:
         cmd += ["--cam"] + [repr(float(v)) for part in cam for v in part]
+    if focal is not None:
+        cmd += ["--focal", repr(float(focal))]
+    if sensor is not None:
+        cmd += ["--sensor", repr(float(sensor))]
+    for name, value in (defines or {}).items():
+        cmd += ["--define", name, value]
     res = subprocess.run(cmd, check=True, stderr=subprocess.PIPE, text=True)
     accum = np.fromfile(acc_path, dtype=np.float32).reshape(h, w, 4)
     if acc:
@@ -104,6 +123,19 @@ def poses(tex, manifest):
     np.savez_compressed(os.path.join(HERE, "shipped_rgba8_64x36_8frames.npz"), **out)
     manifest["files"]["shipped_rgba8_64x36_8frames.npz"] = {"w": 64, "h": 36, "frames": 8, "targets": "unsized GL_RGBA as FBT.cpp:6 (RGBA8)", "keys": sorted(out)}
     manifest["files"]["spp2.npz"] = {"spp": 2, "declared_patch": "#define SPP 1 -> 2", "keys": sorted(out)}
+
+
+def param_cases(tex, manifest):
+    """Z / AO / path-traced frame of every PARAM_CASES entry: focal length, sensor width and the four #defines that kl_params
+    exposes besides RAY_BOUNCES / SAMPLES / SPP, all away from their defaults. Adds params.npz."""
+    out = {}
+    for name, c in PARAM_CASES.items():
+        for mode, mname in ((2, "z"), (0, "ao"), (1, "pt")):
+            img, _ = run_ref(c["w"], c["h"], mode, c["frame"], 1, tex, samples=64, cam=c["cam"], focal=c["focal"], sensor=c["sensor"],
+                             defines=c["defines"])
+            out["%s_%s_f%d" % (name, mname, c["frame"])] = img[0, :, :, :3].copy()
+    np.savez_compressed(os.path.join(HERE, "params.npz"), **out)
+    manifest["files"]["params.npz"] = {"cases": PARAM_CASES, "declared_patch": "the named #define lines of RawFrame.glsl rewritten", "keys": sorted(out)}
 
 
 def jpeg_cases():
@@ -167,6 +199,7 @@ def main():
     if not os.path.exists(BIN):
         sys.exit("build oracle/_ref/glsl_ref first: make -C oracle ref")
     only_poses = len(sys.argv) > 1 and sys.argv[1] == "poses"     # adds poses.npz / spp2.npz and leaves the other files alone
+    only_params = len(sys.argv) > 1 and sys.argv[1] == "params"   # adds params.npz and leaves the other files alone
     # The two data files the reference host loads (GLSL_Renderer.cpp:237,240), decoded with the
     # stb_image.h the reference vendors (what Image::f_load calls), kept as test data. Background.png
     # is a real PNG (lossless: any decoder gives these bytes) and is kept as a file; "Texture.png" is
@@ -188,13 +221,14 @@ def main():
            "albedo": (tx_raw, tx.shape[1], tx.shape[0], tx.shape[2])}
     manifest = {"generator": "tests/golden/make_golden.py", "harness": "oracle/ref_harness.c",
                 "deviations": ["RGBA32F attachments", "vec3 col = vec3(0)", "ping-pong accumulation"], "files": {}}
-    if only_poses:
+    if only_poses or only_params:
         manifest = json.load(open(os.path.join(HERE, "MANIFEST.json")))
-        poses(tex, manifest)
+        (poses if only_poses else param_cases)(tex, manifest)
         with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
         return
     poses(tex, manifest)
+    param_cases(tex, manifest)
     frames = [0, 1, 5, 15]
     info = ""
     for (w, h) in ((64, 36), (160, 90)):

@@ -242,6 +242,26 @@ def test_other_camera_poses_against_the_reference_shader(pose, textures, oracle_
                 check_pose_image(key, got[..., :3], g[key])
 
 
+@pytest.mark.parametrize("case", ["lens", "near"])
+def test_lens_and_shader_defines_against_the_reference_shader(case, textures, oracle_builtin):
+    """Focal length, sensor width and kl_params' hdri_strength / ao_length / max_dist / eps (the shader's #defines,
+    RawFrame.glsl:32-40), all away from their defaults: the HIP path against the reference shader run with those lines
+    rewritten (budgets shared with the oracle's test) and bit for bit against the oracle, both intersect back ends."""
+    from test_oracle_golden import check_param_image, param_case
+    g = golden("params.npz")
+    cam, w, h, f, kw = param_case(case)
+    modes = {"z": kl.MODE_Z, "ao": kl.MODE_AO, "pt": kl.MODE_PT}
+    for accel in (kl.ACCEL_BRUTE, kl.ACCEL_BVH):
+        with make_renderer(w, h, textures, max_frames=0, accel=accel, **kw) as r:
+            r.set_camera(kl_camera(cam))
+            for key in sorted(k for k in g.files if k.startswith(case + "_")):
+                mode = modes[key.split("_")[1]]
+                got = render_raw(r, mode, f)
+                p = ko.default_params(width=w, height=h, mode=KO_MODE[mode], max_frames=0, **kw)
+                assert_bitexact(got, oracle_builtin.render_raw(cam, p, f), "%s accel %d" % (key, accel))
+                check_param_image(key, got[..., :3], g[key])
+
+
 def test_spp_grid(textures, oracle_builtin):
     """kl_params::spp_grid = 2 (#define SPP 2, RawFrame.glsl:37,434-440,446-453): against the reference shader run with that
     define rewritten, bit for bit against the oracle, with the camera rays traced per frame and shared by a batch's frames,

@@ -7,11 +7,13 @@ llvmpipe's polynomial sin/cos send the second AO ray to another surface. Path tr
 mean absolute error of clamp(x,0,1) (what PostProcess.glsl:38 puts on screen), because
 llvmpipe's atan/acos approximations move ~0.3 % of environment lookups by one texel.
 """
+import os
+
 import numpy as np
 import pytest
 
 import kloracle as ko
-from conftest import frac_within_rel, golden, mae_clamped
+from conftest import GOLDEN, frac_within_rel, golden, mae_clamped
 
 # converged-image bounds (4096 spp), shared with the GPU test of the same golden: mean absolute error of
 # clamp(x,0,1), largest absolute difference, relative tolerance and the fraction of pixels that must meet it.
@@ -184,6 +186,48 @@ def test_spp_grid_two(oracle_builtin):
         p = ko.default_params(width=w, height=h, mode=MODES[mode], max_frames=0, spp=2)
         out = ko.render_mean(oracle_builtin, cam, p, 4) if f == "mean4" else oracle_builtin.render_raw(cam, p, int(f[1:]))
         check_spp2_image(key, out[..., :3], g[key])
+
+
+# ---- lens and #defines away from their defaults (tests/golden/make_golden.py: PARAM_CASES, kept in MANIFEST.json) ----
+# path traced: (fraction of pixels within 1e-4 relative, bound on the MAE of clamp(x,0,1)); measured 0.9974 / 3.3e-6 and
+# 0.9759 / 0 ("near" ends most paths in the environment, at three times its strength: every flipped texel shows)
+PARAM_PT_BUDGET = {"lens": (0.996, 2e-5), "near": (0.97, 1e-5)}
+
+
+def param_case(name):
+    """camera, oracle parameters and frame of one PARAM_CASES entry"""
+    import json
+    c = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))["files"]["params.npz"]["cases"][name]
+    cam = ko.default_camera()
+    for k in range(3):
+        cam.pos[k], cam.front[k], cam.up[k] = c["cam"][0][k], c["cam"][1][k], c["cam"][2][k]
+    cam.focal, cam.sensor = c["focal"], c["sensor"]
+    d = c["defines"]
+    kw = dict(ao_length=float(d["AO_LENGTH"]), hdri_strength=float(d["HDRI_STRENGTH"]), eps=float(d["EPSILON"]), max_dist=float(d["MAX_DIST"]))
+    return cam, c["w"], c["h"], c["frame"], kw
+
+
+def check_param_image(key, out, ref):
+    case, mode = key.split("_")[0], key.split("_")[1]
+    if mode == "z":
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), key
+    elif mode == "ao":
+        assert frac_within_rel(out, ref) == 1.0 and np.abs(out - ref).max() <= 3e-6, key      # measured max |d| 7.7e-7
+    else:
+        frac, mae = PARAM_PT_BUDGET[case]
+        assert frac_within_rel(out, ref) >= frac, key
+        assert mae_clamped(out, ref) <= mae, key
+
+
+@pytest.mark.parametrize("case", ["lens", "near"])
+def test_lens_and_shader_defines(case, oracle_builtin):
+    """iCameraFocalLength / iCameraSensorWidth and the #defines HDRI_STRENGTH, AO_LENGTH, MAX_DIST, EPSILON
+    (RawFrame.glsl:32-40), every one away from its default: the reference shader ran with those lines rewritten."""
+    g = golden("params.npz")
+    cam, w, h, f, kw = param_case(case)
+    for key in sorted(k for k in g.files if k.startswith(case + "_")):
+        p = ko.default_params(width=w, height=h, mode=MODES[key.split("_")[1]], max_frames=0, **kw)
+        check_param_image(key, oracle_builtin.render_raw(cam, p, f)[..., :3], g[key])
 
 
 def check_shipped_rgba8(key, acc, ref8):
