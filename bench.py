@@ -351,6 +351,17 @@ def main():
         fence()
         elapsed_shared = max_over_ranks(time.perf_counter() - t0)
 
+    # untimed: what handing the finished image to the host costs (device -> host copy of the float accumulation over PCIe);
+    # `value` has inputs and outputs resident in HBM, this is the figure for a caller that reads every step's image back
+    readback_ms = None
+    if rank == 0:
+        r.synchronize()
+        r.read_accum()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            r.read_accum()
+        readback_ms = 1e3 * (time.perf_counter() - t0) / 3
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         cpu = cpu_baseline(scene, (bg, tx), width, height, args.bounces, args.cpu_seconds)
@@ -372,6 +383,7 @@ def main():
             "mrays_per_s": rays_total / elapsed / 1e6, "rays_per_sample": rays_total / samples_total,
             "value_shared_camera_rays": samples_total / elapsed_shared if elapsed_shared else None,
             "ms_per_step_shared_camera_rays": 1e3 * elapsed_shared / args.steps if elapsed_shared else None,
+            "host_readback_ms": round(readback_ms, 3), "value_with_host_readback": samples_total / (elapsed + 1e-3 * readback_ms * args.steps),
             "config": {"workload": "%s, %dx%d, %d spp, %d bounces, path-traced" % (pre["name"], width, height, frames_total, args.bounces),
                        "triangles": int(n_tris), "analytic_spheres": int(n_spheres), "bvh_nodes": int(bvh.nodes), "bvh_max_depth": int(bvh.max_depth),
                        "bvh_build_s": round(bvh.build_seconds, 4),
