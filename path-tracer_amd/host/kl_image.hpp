@@ -13,7 +13,8 @@ struct Image {
     int width = 0, height = 0, channels = 0;
 
     // Chosen by the file's first bytes, not its name, as stb_image does ("resources/Texture.png" holds JPEG data).
-    // PNG: 8-bit grey / RGB / RGBA, non-interlaced. JPEG: baseline Huffman, grey or three components. false on failure.
+    // PNG: every colour type and bit depth, non-interlaced, reduced to 8 bits per sample the way stb_image does (1 to 4
+    // channels). JPEG: baseline Huffman, grey or three components. false on failure.
     bool f_load(const std::string &path);
     // raw dump written by the tests: width*height*channels bytes
     bool f_load_raw(const std::string &path, int w, int h, int c);

@@ -185,12 +185,49 @@ def jpeg_cases():
         out[name + "__stb"] = np.fromfile(raw, dtype=np.uint8).reshape(h, w, cc)
         made.append(name)
     np.savez_compressed(os.path.join(HERE, "jpeg_stb.npz"), **out)
+    # PNG files of every kind Pillow writes (colour types 0, 2, 3, 4, 6; 1 / 2 / 4 / 8 / 16 bits; palette and colour-key tRNS),
+    # with the bytes stb_image reduces each to: known answers for the host's PNG reader beyond 8-bit RGB(A)
+    pal = Image.fromarray(base[:31, :45]).quantize(colors=16)
+    pal4 = Image.fromarray(base[:31, :45]).quantize(colors=4)
+    pal2 = Image.fromarray(base[:31, :45]).quantize(colors=2)
+    png_cases = {
+        "grey8_37x29": (Image.fromarray(base[:29, :37, 0]), {}),
+        "grey1_45x31": (Image.fromarray(base[:31, :45, 0] > 127), {}),
+        "grey16_20x17": (Image.fromarray((base[:17, :20, 0].astype(np.uint16) * 257 + 13).astype(np.uint16)), {}),
+        "greyalpha_21x13": (Image.fromarray(base[:13, :21, :2], "LA"), {}),
+        "rgb8_33x19": (Image.fromarray(base[:19, :33]), {}),
+        "rgba8_17x23": (Image.fromarray(np.dstack([base[:23, :17], base[:23, :17, 0]])), {}),
+        "pal8_45x31": (Image.fromarray(base[:31, :45]).quantize(colors=200), {}),
+        "pal4_45x31": (pal, {"bits": 4}),
+        "pal2_45x31": (pal4, {"bits": 2}),
+        "pal1_45x31": (pal2, {"bits": 1}),
+        "pal4_trns": (pal, {"bits": 4, "transparency": bytes([0, 64, 128, 255, 200])}),
+        "grey8_key": (Image.fromarray((base[:29, :37, 0] // 32 * 32).astype(np.uint8)), {"transparency": 96}),
+        "rgb8_key": (Image.fromarray((base[:19, :33] // 128 * 128).astype(np.uint8)), {"transparency": (128, 0, 128)}),
+    }
+    pout, pmade = {}, []
+    for name, (img, kw) in png_cases.items():
+        buf = io.BytesIO()
+        try:
+            img.save(buf, "PNG", **kw)
+        except Exception as e:
+            print("skipped", name, e)
+            continue
+        png, raw = os.path.join(TMP, "kl_case.png"), os.path.join(TMP, "kl_case.raw")
+        open(png, "wb").write(buf.getvalue())
+        ww, hh, cc = map(int, subprocess.run([stb, png, raw], check=True, stdout=subprocess.PIPE, text=True).stdout.split())
+        pout[name + "__png"] = np.frombuffer(buf.getvalue(), dtype=np.uint8)
+        pout[name + "__stb"] = np.fromfile(raw, dtype=np.uint8).reshape(hh, ww, cc)
+        pmade.append("%s:%dch" % (name, cc))
+    np.savez_compressed(os.path.join(HERE, "png_stb.npz"), **pout)
     shutil.copyfile(os.path.join(REF, "resources", "Texture.png"), os.path.join(HERE, "assets", "Texture.png"))
     manifest = json.load(open(os.path.join(HERE, "MANIFEST.json")))
     manifest["files"]["jpeg_stb.npz"] = {"cases": made, "encoder": "Pillow %s" % Image.__version__ if hasattr(Image, "__version__") else "Pillow",
                                          "decoder": "external/stb_image.h of the reference through oracle/stb_decode.c"}
+    manifest["files"]["png_stb.npz"] = {"cases": pmade, "encoder": "Pillow", "decoder": "external/stb_image.h of the reference through oracle/stb_decode.c"}
     json.dump(manifest, open(os.path.join(HERE, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
     print("jpeg_stb.npz:", made)
+    print("png_stb.npz:", pmade)
 
 
 def main():

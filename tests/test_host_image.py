@@ -16,6 +16,8 @@ from conftest import GOLDEN, ROOT
 BENCH = os.path.join(ROOT, "path-tracer_amd", "bin", "kl_bench")
 CASES = np.load(os.path.join(GOLDEN, "jpeg_stb.npz"))
 NAMES = sorted(k[:-6] for k in CASES.files if k.endswith("__jpeg"))
+PNG_CASES = np.load(os.path.join(GOLDEN, "png_stb.npz"))
+PNG_NAMES = sorted(k[:-5] for k in PNG_CASES.files if k.endswith("__png"))
 
 
 def decode(path, tmp_path):
@@ -42,6 +44,17 @@ def test_jpeg_cases_match_stb_image(name, tmp_path):
     got = decode(jpg, tmp_path)
     assert got is not None
     assert np.array_equal(got, CASES[name + "__stb"])
+
+
+@pytest.mark.parametrize("name", PNG_NAMES)
+def test_png_kinds_match_stb_image(name, tmp_path):
+    """grey 1 / 8 / 16 bit, grey + alpha, RGB, RGBA, palettes of 1 / 2 / 4 / 8 bits, palette and colour-key transparency: the
+    channel count and the bytes stb_image reduces each file to"""
+    png = tmp_path / (name + ".png")
+    png.write_bytes(PNG_CASES[name + "__png"].tobytes())
+    got = decode(png, tmp_path)
+    assert got is not None
+    assert got.shape == PNG_CASES[name + "__stb"].shape and np.array_equal(got, PNG_CASES[name + "__stb"])
 
 
 def test_png_still_goes_through_the_png_reader(tmp_path):

@@ -82,6 +82,17 @@ def main():
                     for pos in rng.integers(2, len(jpg), size=int(rng.integers(1, 6))):
                         dmg[int(pos)] = int(rng.integers(0, 256))
                     put("%s.d%d.jpg" % (key, k), bytes(dmg))
+            pngs = np.load(os.path.join(ROOT, "tests", "golden", "png_stb.npz"))
+            for key in pngs.files:
+                if not key.endswith("__png"):
+                    continue
+                png_bytes = pngs[key].tobytes()
+                put(key + ".png", png_bytes)
+                for k in range(8):                        # damaged headers, palettes and chunk lengths (CRCs are not checked)
+                    dmg = bytearray(png_bytes)
+                    for pos in rng.integers(8, min(len(dmg), 120), size=int(rng.integers(1, 4))):
+                        dmg[int(pos)] = int(rng.integers(0, 256))
+                    put("%s.d%d.png" % (key, k), bytes(dmg))
             put("huge.jpg", bytes.fromhex("ffd8ffc0000b08ffffffff01011100ffda0008010100003f00") + rng.bytes(64))
             put("soi.jpg", b"\xff\xd8\xff")
             import zlib
