@@ -262,6 +262,23 @@ def test_lens_and_shader_defines_against_the_reference_shader(case, textures, or
                 check_param_image(key, got[..., :3], g[key])
 
 
+def test_reference_screenshot_zdepth_is_reproduced():
+    """The upstream author's screenshot of the application in ZDepth view (tests/golden/assets/S7.png, the only output of
+    the reference on a real GPU that its repository holds): the HIP path at the camera pose fitted to it, 3840x1974, through
+    the shipped application's 8-bit attachments and kl_resolve (PostProcess.glsl:38); two frames, so the running mean through
+    RGBA8 is exercised; both intersect back ends. Budgets shared with the oracle's test."""
+    from test_oracle_golden import check_s7, s7_camera
+    for accel in (kl.ACCEL_BRUTE, kl.ACCEL_BVH):
+        with make_renderer(3840, 1974, None, max_frames=0, accel=accel) as r:
+            r.set_accum_mode(kl.ACCUM_MEAN_UNORM8)
+            r.set_camera(kl_camera(s7_camera()))
+            r.set_mode(kl.MODE_Z)
+            r.render_frames(2)
+            rgba8 = r.resolve()
+            assert rgba8.shape == (1974, 3840, 4) and np.array_equal(rgba8[..., 0], rgba8[..., 1]) and (rgba8[..., 3] == 255).all()
+            check_s7(rgba8[..., 0])
+
+
 def test_spp_grid(textures, oracle_builtin):
     """kl_params::spp_grid = 2 (#define SPP 2, RawFrame.glsl:37,434-440,446-453): against the reference shader run with that
     define rewritten, bit for bit against the oracle, with the camera rays traced per frame and shared by a batch's frames,

@@ -230,6 +230,55 @@ def test_lens_and_shader_defines(case, oracle_builtin):
         check_param_image(key, oracle_builtin.render_raw(cam, p, f)[..., :3], g[key])
 
 
+# ---- the upstream author's own screenshot (resources/Screenshots/S7.png): the application in ZDepth view on their GPU ----
+# The window's camera state is not recorded anywhere; it was recovered by fitting the five numbers the application's camera has
+# (position, yaw and pitch in the mouse's 0.075-degree steps; Camera.cpp:26-43, GLSL_Renderer.cpp:84-96) to the screenshot with
+# the oracle's ZDepth render. 7.6 M pixels against 5 degrees of freedom: what agrees beyond that is the scene, the ray set-up
+# (focal length, sensor width, the uv arithmetic of RawFrame.glsl:428-429), the quad and sphere tests and 1 - min(t / 50, 0.9).
+S7_POSE = dict(pos=(4.52759, 2.30201, 24.68955), yaw=-97.5, pitch=-0.825, title_bar_rows=45)
+
+
+def s7_camera():
+    """Camera::f_compile (Camera.cpp:35-43) in double precision, narrowed as GLSL_Renderer.cpp:293-297 does"""
+    deg = 0.01745329252
+    yaw, pitch = S7_POSE["yaw"], S7_POSE["pitch"]
+    z = np.array([np.cos(yaw * deg) * np.cos(pitch * deg), np.sin(pitch * deg), np.sin(yaw * deg) * np.cos(pitch * deg)])
+    z /= np.linalg.norm(z)
+    x = np.cross(z, [0.0, 1.0, 0.0]); x /= np.linalg.norm(x)
+    y = np.cross(x, z); y /= np.linalg.norm(y)
+    cam = ko.default_camera()
+    for k in range(3):
+        cam.pos[k], cam.front[k], cam.up[k] = float(np.float32(S7_POSE["pos"][k])), float(np.float32(z[k])), float(np.float32(y[k]))
+    return cam
+
+
+def s7_client_area():
+    """the screenshot below its title bar, as bytes, rows bottom to top like the render's"""
+    from PIL import Image
+    shot = np.array(Image.open(os.path.join(GOLDEN, "assets", "S7.png")).convert("RGB"))[S7_POSE["title_bar_rows"]:]
+    assert shot.shape == (1974, 3840, 3) and np.array_equal(shot[..., 0], shot[..., 1]) and np.array_equal(shot[..., 0], shot[..., 2])
+    return shot[::-1, :, 0].astype(np.int32)
+
+
+def check_s7(bytes_rendered):
+    """measured with the oracle: 95.25 % of the 7.6 M bytes identical, 97.3 % within one level, 98.3 % within two (the rest are
+    silhouette pixels, 0.4 % of the image is covered in one picture and not the other)"""
+    want = s7_client_area()
+    d = np.abs(bytes_rendered.astype(np.int32) - want)
+    assert (d == 0).mean() >= 0.945 and (d <= 1).mean() >= 0.968 and (d <= 2).mean() >= 0.978
+    assert ((want > 0) != (bytes_rendered > 0)).mean() <= 0.006
+    both = (want > 0) & (bytes_rendered > 0)
+    assert abs((bytes_rendered.astype(np.int32) - want)[both].mean()) <= 0.1            # no brightness bias: measured -0.02 levels
+
+
+def test_reference_screenshot_zdepth(oracle_builtin):
+    """ZDepth at 3840x1974 from the fitted pose against the upstream screenshot, through the 8-bit attachments of the
+    shipped application (a deterministic view: every frame is the same image, so one frame is the accumulation)"""
+    p = ko.default_params(width=3840, height=1974, mode=ko.MODE_Z, max_frames=0)
+    acc = ko.render_mean(oracle_builtin, s7_camera(), p, 1, unorm8=True)[..., 0]
+    check_s7(np.rint(acc * 255.0).astype(np.int32))
+
+
 def check_shipped_rgba8(key, acc, ref8):
     """acc: float mean kept through 8-bit attachments (values on the byte grid); ref8: the reference run's bytes"""
     got8 = np.rint(acc * 255.0).astype(np.int32)
