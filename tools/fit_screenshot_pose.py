@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Recovers the camera of the upstream screenshot tests/golden/assets/S7.png (the reference application in ZDepth view) by
+fitting the oracle's ZDepth render to it. The application's camera has five numbers: position and yaw / pitch
+(Camera.cpp:26-43), the angles moving in steps of the mouse sensitivity, 0.075 degrees (GLSL_Renderer.cpp:24,92).
+
+  1. random search at 1/12 resolution over a box of poses outside the room's open front (mean absolute difference),
+  2. Nelder-Mead from the best few,
+  3. refinement on the smooth parts of the picture only (squared depth difference where neither image has an edge: the
+     silhouettes make the all-pixel objective rugged),
+  4. yaw and pitch snapped to the 0.075-degree grid, position refined at 1/3 and at full resolution.
+
+CPU only (the oracle), a few minutes on 8 cores. Prints the pose that tests/test_oracle_golden.py holds as S7_POSE."""
+import json
+import os
+import sys
+
+import numpy as np
+from PIL import Image
+from scipy import ndimage
+from scipy.optimize import minimize
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import kloracle as ko  # noqa: E402
+
+DEG = 0.01745329252
+TITLE_BAR = 45
+SHOT = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "assets", "S7.png")).convert("RGB"))[TITLE_BAR:, :, 0].astype(np.float32) / 255.0
+H, W = SHOT.shape
+SCENE = ko.Scene(builtin=True)
+
+
+def camera(p):
+    yaw, pitch = p[3], p[4]
+    z = np.array([np.cos(yaw * DEG) * np.cos(pitch * DEG), np.sin(pitch * DEG), np.sin(yaw * DEG) * np.cos(pitch * DEG)])
+    z /= np.linalg.norm(z)
+    x = np.cross(z, [0, 1, 0]); x /= np.linalg.norm(x)
+    y = np.cross(x, z); y /= np.linalg.norm(y)
+    cam = ko.default_camera()
+    for k in range(3):
+        cam.pos[k], cam.front[k], cam.up[k] = float(np.float32(p[k])), float(np.float32(z[k])), float(np.float32(y[k]))
+    return cam
+
+
+class Level:
+    """the screenshot point-sampled at 1/s resolution, rows bottom to top, and the two objectives at that resolution"""
+
+    def __init__(self, s):
+        self.s, self.w, self.h = s, W // s, H // s
+        ys = ((np.arange(self.h) + 0.5) * H / self.h).astype(int)
+        xs = ((np.arange(self.w) + 0.5) * W / self.w).astype(int)
+        self.target = SHOT[ys][:, xs][::-1]
+        self.edge = 0.004 * s / 4
+        g = np.hypot(*np.gradient(self.target))
+        self.smooth = ndimage.binary_erosion((g < self.edge) & (self.target > 0), iterations=2)
+
+    def render(self, p):
+        prm = ko.default_params(width=self.w, height=self.h, mode=ko.MODE_Z, max_frames=0)
+        return SCENE.render_raw(camera(p), prm, 0)[..., 0]
+
+    def l1(self, p):
+        return float(np.abs(self.render(p) - self.target).mean())
+
+    def smooth_l2(self, p):
+        img = self.render(p)
+        m = self.smooth & (img > 0) & (np.hypot(*np.gradient(img)) < self.edge)
+        if m.sum() < 0.3 * self.smooth.sum():
+            return 1.0
+        d = (img - self.target)[m]
+        return float((d * d).mean()) + 0.02 * float(1 - m.sum() / self.smooth.sum()) ** 2
+
+
+def main():
+    rng = np.random.default_rng(0)
+    coarse = Level(12)
+    lo, hi = np.array([0, 0, 12, -125, -12.0]), np.array([14, 5, 40, -85, 6.0])
+    cands = sorted(((coarse.l1(p), p) for p in (lo + (hi - lo) * rng.random(5) for _ in range(6000))), key=lambda t: t[0])
+    best = min((minimize(coarse.l1, p, method="Nelder-Mead", options=dict(xatol=1e-5, fatol=1e-8, maxiter=3000)) for _, p in cands[:6]),
+               key=lambda r: r.fun)
+    print("coarse", best.x.round(4).tolist(), best.fun)
+    mid = Level(4)
+    runs = []
+    for it in range(6):
+        p0 = best.x + (rng.normal(0, [0.2, 0.2, 0.4, 0.3, 0.4]) if it else 0)
+        r = minimize(mid.smooth_l2, p0, method="Powell", options=dict(xtol=1e-7, ftol=1e-12, maxiter=4000))
+        runs.append(minimize(mid.smooth_l2, r.x, method="Nelder-Mead", options=dict(xatol=1e-6, fatol=1e-13, maxiter=3000)))
+    p = min(runs, key=lambda r: r.fun).x
+    print("smooth", p.round(4).tolist())
+    yaw, pitch = round((p[3] + 90) / 0.075) * 0.075 - 90, round(p[4] / 0.075) * 0.075
+    pos = p[:3]
+    for s in (3, 1):
+        lv = Level(s)
+        f = lambda q: lv.smooth_l2([q[0], q[1], q[2], yaw, pitch])  # noqa: E731
+        pos = minimize(f, pos, method="Powell", options=dict(xtol=1e-7, ftol=1e-13, maxiter=3000)).x
+        pos = minimize(f, pos, method="Nelder-Mead", options=dict(xatol=1e-6, fatol=1e-14, maxiter=3000)).x
+    full = Level(1)
+    b = np.rint(full.render([*pos, yaw, pitch]) * 255).astype(int)
+    t = np.rint(full.target * 255).astype(int)
+    d = np.abs(b - t)
+    print(json.dumps({"pos": np.round(pos, 5).tolist(), "yaw": yaw, "pitch": pitch, "bytes_equal": float((d == 0).mean()),
+                      "within_1": float((d <= 1).mean()), "within_2": float((d <= 2).mean())}))
+
+
+if __name__ == "__main__":
+    main()
