@@ -6,12 +6,14 @@ llvmpipe goldens the tolerances of tests/test_oracle_golden.py apply.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
 import klrender as kl
 import kloracle as ko
-from conftest import frac_within_rel, golden, mae_clamped
+from conftest import GOLDEN, frac_within_rel, golden, mae_clamped
 
 pytestmark = pytest.mark.gpu
 
@@ -277,6 +279,41 @@ def test_reference_screenshot_zdepth_is_reproduced():
             rgba8 = r.resolve()
             assert rgba8.shape == (1974, 3840, 4) and np.array_equal(rgba8[..., 0], rgba8[..., 1]) and (rgba8[..., 3] == 255).all()
             check_s7(rgba8[..., 0])
+
+
+# camera of the upstream screenshot S4.png (the path-traced view of the same session), fitted with GPU renders
+# (tools/fit_screenshot_s4.py): position, yaw (on the mouse grid: -90 - 299 x 0.075), pitch
+S4_POSE = (10.60763, 4.05823, 29.53472, -112.42508, -0.58587)
+
+
+def test_reference_screenshot_pathtraced_is_reproduced(textures):
+    """The upstream author's screenshot of the path-traced view (tests/golden/assets/S4.png; 3840x1974 client area): the
+    shipped pipeline (30 frames, SAMPLES freeze, 8-bit attachments, PostProcess clamp) from the fitted pose. Sky, the room's
+    outside and most of the textured wall come out byte for byte (84 % of all pixels, all three channels); the interior is
+    noise in both pictures and the two noises are independent (the reference ran with other random numbers than frames 0..29
+    of today's shader give: the difference has no dip at any frame count), so it is compared by 32 x 32 block means.
+    Measured: 84.2 % of pixels identical, 95.3 % within 8 levels; block means of the quiet part 0.06 levels apart (max 2.6),
+    of the noisy part 0.97 (bias +1.0 / +0.9 / +0.7: 0.5 % brighter)."""
+    from PIL import Image
+    from test_oracle_golden import S7_POSE, app_camera
+    shot = np.array(Image.open(os.path.join(GOLDEN, "assets", "S4.png")).convert("RGB"))[S7_POSE["title_bar_rows"]:][::-1].astype(np.int32)
+    cam = app_camera(S4_POSE[:3], S4_POSE[3], S4_POSE[4])
+    with make_renderer(3840, 1974, textures) as r:                     # max_frames stays 30 = #define SAMPLES
+        r.set_accum_mode(kl.ACCUM_MEAN_UNORM8)
+        r.set_camera(kl_camera(cam))
+        r.set_mode(kl.MODE_PT)
+        r.render_frames(40)                                            # frames 30..39 change nothing
+        img = r.resolve()[..., :3].astype(np.int32)
+    d = np.abs(img - shot).max(axis=2)
+    assert (d == 0).mean() >= 0.835 and (d <= 8).mean() >= 0.948
+    b = 32
+    h, w = (1974 // b) * b, (3840 // b) * b
+    means = lambda a: a[:h, :w].astype(np.float64).reshape(h // b, b, w // b, b, 3).mean(axis=(1, 3))  # noqa: E731
+    dm = means(img) - means(shot)
+    noisy = d[:h, :w].reshape(h // b, b, w // b, b).mean(axis=(1, 3)) > 4
+    assert 0.05 <= noisy.mean() <= 0.09
+    assert np.abs(dm[~noisy]).mean() <= 0.1 and np.abs(dm[~noisy]).max() <= 4.0
+    assert np.abs(dm[noisy]).mean() <= 1.5 and np.abs(dm[noisy].mean(axis=0)).max() <= 1.6
 
 
 def test_spp_grid(textures, oracle_builtin):

@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Recovers the camera of the upstream screenshot tests/golden/assets/S4.png (the reference application in its path-traced
+view) by fitting GPU renders to it, then renders the view as the shipped application would have shown it (30 frames through
+8-bit attachments, SAMPLES freeze, PostProcess clamp) at the window's 3840x1974 and compares byte for byte.
+
+Needs an MI355X (thousands of small renders). Stages: random search at 1/16 resolution, Nelder-Mead / Powell refinements at
+1/8 and 1/4 on blurred images (the low-resolution renders have their own noise: the hash RNG is keyed by pixel coordinates),
+final render at full resolution. Prints one JSON line; writes the render and a difference picture under gpurun_out/."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+from PIL import Image
+from scipy import ndimage
+from scipy.optimize import minimize
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
+import klrender as kl  # noqa: E402
+
+DEG = 0.01745329252
+ASSETS = os.path.join(ROOT, "tests", "golden", "assets")
+SHOT = np.array(Image.open(os.path.join(ASSETS, "S4.png")).convert("RGB"))[45:][::-1].astype(np.float32)     # client area, rows bottom to top
+H, W = SHOT.shape[:2]
+BG = np.array(Image.open(os.path.join(ASSETS, "Background.png")))
+TX = np.load(os.path.join(ASSETS, "Texture_stb_rgb8.npz"))["rgb"]
+
+
+def camera(p):
+    yaw, pitch = p[3], p[4]
+    z = np.array([np.cos(yaw * DEG) * np.cos(pitch * DEG), np.sin(pitch * DEG), np.sin(yaw * DEG) * np.cos(pitch * DEG)])
+    z /= np.linalg.norm(z)
+    x = np.cross(z, [0, 1, 0]); x /= np.linalg.norm(x)
+    y = np.cross(x, z); y /= np.linalg.norm(y)
+    cam = kl.Camera()
+    for k in range(3):
+        cam.pos[k], cam.front[k], cam.up[k] = float(np.float32(p[k])), float(np.float32(z[k])), float(np.float32(y[k]))
+    cam.focal, cam.sensor = 0.05, 0.036
+    return cam
+
+
+class Level:
+    def __init__(self, s, frames, sigma):
+        self.s, self.w, self.h, self.frames, self.sigma = s, W // s, H // s, frames, sigma
+        # the screenshot averaged over s x s blocks (cropping the few rows that do not fill a block)
+        t = SHOT[:self.h * s, :self.w * s].reshape(self.h, s, self.w, s, 3).mean(axis=(1, 3))
+        self.target = self.blur(t)
+        self.r = kl.Renderer(self.w, self.h)
+        self.r.load_builtin_scene()
+        self.r.upload_texture(kl.TEX_HDRI, BG)
+        self.r.upload_texture(kl.TEX_ALBEDO, TX)
+        self.r.update_params(max_frames=0)
+        self.r.set_accum_mode(kl.ACCUM_MEAN_UNORM8)
+        self.r.set_mode(kl.MODE_PT)
+        self.evals = 0
+
+    def blur(self, img):
+        return ndimage.gaussian_filter(img, (self.sigma, self.sigma, 0)) if self.sigma else img
+
+    def render(self, p):
+        self.r.set_camera(camera(p))
+        self.r.render_frames(self.frames)
+        return self.r.resolve()[..., :3].astype(np.float32)
+
+    def cost(self, p):
+        self.evals += 1
+        if not (-89 < p[4] < 89):
+            return 1e3
+        return float(np.abs(self.blur(self.render(p)) - self.target).mean())
+
+
+def main():
+    t0 = time.time()
+    rng = np.random.default_rng(0)
+    lv = Level(16, 30, 1.0)
+    lo, hi = np.array([2.0, 2.0, 6.0, -140.0, -30.0]), np.array([16.0, 10.0, 45.0, -92.0, 0.0])
+    cands = []
+    for i in range(8000):
+        p = lo + (hi - lo) * rng.random(5)
+        cands.append((lv.cost(p), p))
+        if i % 1000 == 999:
+            print("search", i + 1, round(min(c for c, _ in cands), 3), round(time.time() - t0, 1), flush=True)
+    cands.sort(key=lambda t: t[0])
+    runs = []
+    for c, p in cands[:8]:
+        r = minimize(lv.cost, p, method="Nelder-Mead", options=dict(xatol=1e-4, fatol=1e-5, maxiter=1500))
+        runs.append(r)
+        print("nm16", np.round(p, 2).tolist(), "->", np.round(r.x, 3).tolist(), round(r.fun, 4), flush=True)
+    p = min(runs, key=lambda r: r.fun).x
+    for s, frames, sigma in ((8, 30, 1.5), (4, 30, 2.0), (4, 30, 1.0)):
+        lv = Level(s, frames, sigma)
+        for _ in range(2):
+            p = minimize(lv.cost, p, method="Powell", options=dict(xtol=1e-6, ftol=1e-7, maxiter=3000)).x
+            r = minimize(lv.cost, p, method="Nelder-Mead", options=dict(xatol=1e-6, fatol=1e-8, maxiter=2000, adaptive=True))
+            p = r.x
+        print("level", s, sigma, json.dumps(np.round(p, 5).tolist()), round(r.fun, 4), lv.evals, round(time.time() - t0, 1), flush=True)
+    out = final(p)
+    out["seconds"] = round(time.time() - t0, 1)
+    print(json.dumps(out))
+
+
+def block_stats(img, shot, b=32):
+    """The room's interior is noise in both pictures, and the two noises are independent (the difference keeps falling as
+    more frames are added, with no dip at any frame count), so there the pictures are compared by the means of 32 x 32 blocks.
+    "noisy" = blocks whose pixels differ by more than 4 levels on average."""
+    h, w = (H // b) * b, (W // b) * b
+    bm = lambda a: a[:h, :w].astype(np.float64).reshape(h // b, b, w // b, b, 3).mean(axis=(1, 3))  # noqa: E731
+    d = bm(img) - bm(shot)
+    noisy = np.abs(img.astype(np.int32) - shot.astype(np.int32)).max(axis=2)[:h, :w].reshape(h // b, b, w // b, b).mean(axis=(1, 3)) > 4
+    return {"noisy_fraction": float(noisy.mean()), "noisy_mae": float(np.abs(d[noisy]).mean()), "noisy_bias_rgb": d[noisy].mean(axis=0).round(3).tolist(),
+            "noisy_p95": float(np.percentile(np.abs(d[noisy]), 95)), "quiet_mae": float(np.abs(d[~noisy]).mean()), "quiet_max": float(np.abs(d[~noisy]).max())}
+
+
+def final(p, tag="s4"):
+    """the view as shipped: 30 frames (the SAMPLES freeze), 8-bit attachments, at the window's own resolution"""
+    r = kl.Renderer(W, H)
+    r.load_builtin_scene()
+    r.upload_texture(kl.TEX_HDRI, BG)
+    r.upload_texture(kl.TEX_ALBEDO, TX)
+    r.set_accum_mode(kl.ACCUM_MEAN_UNORM8)
+    r.set_mode(kl.MODE_PT)
+    r.set_camera(camera(p))
+    r.render_frames(40)                     # frames 30..39 are frozen (max_frames = SAMPLES = 30): the picture stops changing
+    img = r.resolve()[..., :3].astype(np.int32)
+    d = np.abs(img - SHOT.astype(np.int32)).max(axis=2)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    Image.fromarray(img[::-1].astype(np.uint8)).save(os.path.join(ROOT, "gpurun_out", tag + "_render.png"))
+    Image.fromarray(np.clip(d[::-1] * 8, 0, 255).astype(np.uint8)).resize((W // 2, H // 2)).save(os.path.join(ROOT, "gpurun_out", tag + "_diff.png"))
+    blocks = block_stats(img, SHOT)
+    return {"blocks_32x32": blocks, "pose": np.round(p, 5).tolist(), "pixels_equal": float((d == 0).mean()), "within_1": float((d <= 1).mean()),
+            "within_2": float((d <= 2).mean()), "within_8": float((d <= 8).mean()), "mae_levels": float(np.abs(img - SHOT).mean())}
+
+
+def refine_full(p):
+    """last stage: the all-pixel mean absolute difference at the window's own resolution, as shipped"""
+    r = kl.Renderer(W, H)
+    r.load_builtin_scene()
+    r.upload_texture(kl.TEX_HDRI, BG)
+    r.upload_texture(kl.TEX_ALBEDO, TX)
+    r.set_accum_mode(kl.ACCUM_MEAN_UNORM8)
+    r.set_mode(kl.MODE_PT)
+    shot = SHOT.astype(np.int16)
+    n = [0]
+    t0 = time.time()
+
+    def cost(q):
+        r.set_camera(camera(q))
+        r.render_frames(30)
+        n[0] += 1
+        c = float(np.abs(r.resolve()[..., :3].astype(np.int16) - shot).mean())
+        if n[0] % 50 == 0:
+            print("full", n[0], round(c, 4), np.round(q, 5).tolist(), round(time.time() - t0, 1), flush=True)
+        return c
+    for _ in range(2):
+        p = minimize(cost, p, method="Nelder-Mead", options=dict(xatol=1e-6, fatol=1e-6, maxiter=400, adaptive=True,
+                     initial_simplex=np.array([p] + [np.array(p) + d for d in np.diag([0.01, 0.01, 0.02, 0.01, 0.01])]))).x
+        p = minimize(cost, p, method="Powell", options=dict(xtol=1e-6, ftol=1e-7, maxiter=300)).x
+    return p
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "refine":
+        q = refine_full(np.array(json.loads(sys.argv[2])))
+        print(json.dumps(final(q, "s4_refined")))
+    elif len(sys.argv) > 1:
+        print(json.dumps(final(json.loads(sys.argv[1]), "s4_given")))
+    else:
+        main()
