@@ -293,7 +293,7 @@ def test_reference_screenshot_pathtraced_is_reproduced(textures):
     noise in both pictures and the two noises are independent (the reference ran with other random numbers than frames 0..29
     of today's shader give: the difference has no dip at any frame count), so it is compared by 32 x 32 block means.
     Measured: 84.2 % of pixels identical, 95.3 % within 8 levels; block means of the quiet part 0.06 levels apart (max 2.6),
-    of the noisy part 0.97 (bias +1.0 / +0.9 / +0.7: 0.5 % brighter)."""
+    of the noisy part 0.97 (bias +1.0 / +0.9 / +0.7: 0.5 % brighter); noise amplitude within 1-2 % of the screenshot's."""
     from PIL import Image
     from test_oracle_golden import S7_POSE, app_camera
     shot = np.array(Image.open(os.path.join(GOLDEN, "assets", "S4.png")).convert("RGB"))[S7_POSE["title_bar_rows"]:][::-1].astype(np.int32)
@@ -314,6 +314,17 @@ def test_reference_screenshot_pathtraced_is_reproduced(textures):
     assert 0.05 <= noisy.mean() <= 0.09
     assert np.abs(dm[~noisy]).mean() <= 0.1 and np.abs(dm[~noisy]).max() <= 4.0
     assert np.abs(dm[noisy]).mean() <= 1.5 and np.abs(dm[noisy].mean(axis=0)).max() <= 1.6
+    # The noise itself: its amplitude (std of the picture minus its 9 x 9 box blur) is that of exactly 30 accumulated frames
+    # (the SAMPLES freeze, RawFrame.glsl:38,426). Measured ours / theirs: floor 15.08 / 15.24, top face 3.88 / 3.86, textured
+    # wall 1.76 / 1.76, outside of the right wall 0.83 / 0.85 (after 10 frames ours would be 25.8 / 6.1 / 2.6 / 1.05).
+    from scipy import ndimage
+    hp = lambda a: a - ndimage.uniform_filter(a.astype(np.float64), (9, 9, 0))  # noqa: E731
+    ours, theirs = hp(img), hp(shot)
+    for name, (y0, y1, x0, x1) in {"top face": (1085, 1115, 2300, 2800), "floor": (1450, 1650, 1500, 2200),
+                                   "textured wall": (1180, 1300, 1700, 1950), "right outside": (1300, 1500, 2500, 2900)}.items():
+        ys, xs = slice(1974 - y1, 1974 - y0), slice(x0, x1)          # picture rows count from the top, buffer rows from the bottom
+        ratio = ours[ys, xs].std() / theirs[ys, xs].std()
+        assert 0.94 <= ratio <= 1.06, (name, ratio)
 
 
 def test_spp_grid(textures, oracle_builtin):
