@@ -266,65 +266,56 @@ def test_lens_and_shader_defines_against_the_reference_shader(case, textures, or
 
 def test_reference_screenshot_zdepth_is_reproduced():
     """The upstream author's screenshot of the application in ZDepth view (tests/golden/assets/S7.png, the only output of
-    the reference on a real GPU that its repository holds): the HIP path at the camera pose fitted to it, 3840x1974, through
+    the reference on a real GPU that its repository holds): the HIP path at the camera pose fitted to it, 3840x2019, through
     the shipped application's 8-bit attachments and kl_resolve (PostProcess.glsl:38); two frames, so the running mean through
     RGBA8 is exercised; both intersect back ends. Budgets shared with the oracle's test."""
-    from test_oracle_golden import check_s7, s7_camera
+    from test_oracle_golden import SHOT_LOST_ROWS, SHOT_RENDER_SIZE, check_s7, s7_camera
     for accel in (kl.ACCEL_BRUTE, kl.ACCEL_BVH):
-        with make_renderer(3840, 1974, None, max_frames=0, accel=accel) as r:
+        with make_renderer(*SHOT_RENDER_SIZE, None, max_frames=0, accel=accel) as r:
             r.set_accum_mode(kl.ACCUM_MEAN_UNORM8)
             r.set_camera(kl_camera(s7_camera()))
             r.set_mode(kl.MODE_Z)
             r.render_frames(2)
             rgba8 = r.resolve()
-            assert rgba8.shape == (1974, 3840, 4) and np.array_equal(rgba8[..., 0], rgba8[..., 1]) and (rgba8[..., 3] == 255).all()
-            check_s7(rgba8[..., 0])
+            assert rgba8.shape == (2019, 3840, 4) and np.array_equal(rgba8[..., 0], rgba8[..., 1]) and (rgba8[..., 3] == 255).all()
+            check_s7(rgba8[SHOT_LOST_ROWS:, :, 0])
 
 
 # camera of the upstream screenshot S4.png (the path-traced view of the same session), fitted with GPU renders
 # (tools/fit_screenshot_s4.py): position, yaw (on the mouse grid: -90 - 299 x 0.075), pitch
-S4_POSE = (10.60763, 4.05823, 29.53472, -112.42508, -0.58587)
+S4_POSE = (10.59404, 4.0598, 29.49413, -112.42508, -0.8288)
 
 
 def test_reference_screenshot_pathtraced_is_reproduced(textures):
-    """The upstream author's screenshot of the path-traced view (tests/golden/assets/S4.png; 3840x1974 client area): the
-    shipped pipeline (30 frames, SAMPLES freeze, 8-bit attachments, PostProcess clamp) from the fitted pose. Sky, the room's
-    outside and most of the textured wall come out byte for byte (84 % of all pixels, all three channels); the interior is
-    noise in both pictures and the two noises are independent (the reference ran with other random numbers than frames 0..29
-    of today's shader give: the difference has no dip at any frame count), so it is compared by 32 x 32 block means.
-    Measured: 84.2 % of pixels identical, 95.3 % within 8 levels; block means of the quiet part 0.06 levels apart (max 2.6),
-    of the noisy part 0.97 (bias +1.0 / +0.9 / +0.7: 0.5 % brighter); noise amplitude within 1-2 % of the screenshot's."""
+    """The upstream author's screenshot of the path-traced view (tests/golden/assets/S4.png): the shipped pipeline (30 frames,
+    SAMPLES freeze, 8-bit attachments, PostProcess clamp) at the window's 3840x2019 from the fitted pose, against the 1974
+    rows the picture shows. The picture is reproduced down to its noise: the hash RNG keyed by (gl_FragCoord, iFrame), frames
+    0..29, the bounce logic, the materials, both textures and the 8-bit running mean, as the author's GPU ran them.
+    Measured: 86.0 % of pixels identical in all three channels, 96.8 % within one level, 98.6 % within two, 99.57 % within
+    eight, mean absolute difference 0.17 levels; the noise (picture minus its 9 x 9 box blur) correlates 0.945 on the floor,
+    0.947 on the room's top, 0.86 on the textured wall, with amplitudes equal to 2 % (what is left are the glass and mirror
+    spheres and paths of many near-mirror bounces, where the two GPUs' sin / cos / sqrt differ in the last bits)."""
     from PIL import Image
-    from test_oracle_golden import S7_POSE, app_camera
+    from scipy import ndimage
+    from test_oracle_golden import S7_POSE, SHOT_LOST_ROWS, SHOT_RENDER_SIZE, app_camera
     shot = np.array(Image.open(os.path.join(GOLDEN, "assets", "S4.png")).convert("RGB"))[S7_POSE["title_bar_rows"]:][::-1].astype(np.int32)
-    cam = app_camera(S4_POSE[:3], S4_POSE[3], S4_POSE[4])
-    with make_renderer(3840, 1974, textures) as r:                     # max_frames stays 30 = #define SAMPLES
+    with make_renderer(*SHOT_RENDER_SIZE, textures) as r:             # max_frames stays 30 = #define SAMPLES
         r.set_accum_mode(kl.ACCUM_MEAN_UNORM8)
-        r.set_camera(kl_camera(cam))
+        r.set_camera(kl_camera(app_camera(S4_POSE[:3], S4_POSE[3], S4_POSE[4])))
         r.set_mode(kl.MODE_PT)
         r.render_frames(40)                                            # frames 30..39 change nothing
-        img = r.resolve()[..., :3].astype(np.int32)
+        img = r.resolve()[SHOT_LOST_ROWS:, :, :3].astype(np.int32)
     d = np.abs(img - shot).max(axis=2)
-    assert (d == 0).mean() >= 0.835 and (d <= 8).mean() >= 0.948
-    b = 32
-    h, w = (1974 // b) * b, (3840 // b) * b
-    means = lambda a: a[:h, :w].astype(np.float64).reshape(h // b, b, w // b, b, 3).mean(axis=(1, 3))  # noqa: E731
-    dm = means(img) - means(shot)
-    noisy = d[:h, :w].reshape(h // b, b, w // b, b).mean(axis=(1, 3)) > 4
-    assert 0.05 <= noisy.mean() <= 0.09
-    assert np.abs(dm[~noisy]).mean() <= 0.1 and np.abs(dm[~noisy]).max() <= 4.0
-    assert np.abs(dm[noisy]).mean() <= 1.5 and np.abs(dm[noisy].mean(axis=0)).max() <= 1.6
-    # The noise itself: its amplitude (std of the picture minus its 9 x 9 box blur) is that of exactly 30 accumulated frames
-    # (the SAMPLES freeze, RawFrame.glsl:38,426). Measured ours / theirs: floor 15.08 / 15.24, top face 3.88 / 3.86, textured
-    # wall 1.76 / 1.76, outside of the right wall 0.83 / 0.85 (after 10 frames ours would be 25.8 / 6.1 / 2.6 / 1.05).
-    from scipy import ndimage
-    hp = lambda a: a - ndimage.uniform_filter(a.astype(np.float64), (9, 9, 0))  # noqa: E731
+    assert (d == 0).mean() >= 0.85 and (d <= 1).mean() >= 0.96 and (d <= 2).mean() >= 0.98 and (d <= 8).mean() >= 0.994
+    assert np.abs(img - shot).mean() <= 0.2
+    hp = lambda a: a[..., 1].astype(np.float64) - ndimage.uniform_filter(a[..., 1].astype(np.float64), (9, 9))  # noqa: E731
     ours, theirs = hp(img), hp(shot)
-    for name, (y0, y1, x0, x1) in {"top face": (1085, 1115, 2300, 2800), "floor": (1450, 1650, 1500, 2200),
-                                   "textured wall": (1180, 1300, 1700, 1950), "right outside": (1300, 1500, 2500, 2900)}.items():
+    for name, (y0, y1, x0, x1, rho) in {"top face": (1085, 1115, 2300, 2800, 0.92), "floor": (1450, 1650, 1500, 2200, 0.92),
+                                        "textured wall": (1180, 1300, 1700, 1950, 0.8)}.items():
         ys, xs = slice(1974 - y1, 1974 - y0), slice(x0, x1)          # picture rows count from the top, buffer rows from the bottom
-        ratio = ours[ys, xs].std() / theirs[ys, xs].std()
-        assert 0.94 <= ratio <= 1.06, (name, ratio)
+        a, b = ours[ys, xs].ravel(), theirs[ys, xs].ravel()
+        assert 0.95 <= a.std() / b.std() <= 1.05, (name, a.std(), b.std())
+        assert np.corrcoef(a, b)[0, 1] >= rho, (name, np.corrcoef(a, b)[0, 1])
 
 
 def test_spp_grid(textures, oracle_builtin):

@@ -231,11 +231,16 @@ def test_lens_and_shader_defines(case, oracle_builtin):
 
 
 # ---- the upstream author's own screenshot (resources/Screenshots/S7.png): the application in ZDepth view on their GPU ----
+# The window: the picture is 3840x2019 = 45 rows of title bar + 1974 rows of image, but the application rendered 3840x2019 and
+# the capture (as tall as the client area, starting at the top of the title bar) lost the image's bottom 45 rows: the per-pixel
+# noise of the path-traced screenshot of the same session lines up with a render's only under that reading (the hash RNG is keyed
+# by gl_FragCoord; tools/fit_screenshot_s4.py).
 # The window's camera state is not recorded anywhere; it was recovered by fitting the five numbers the application's camera has
 # (position, yaw, pitch; Camera.cpp:26-43, GLSL_Renderer.cpp:84-96) to the screenshot with the oracle's ZDepth render
 # (tools/fit_screenshot_pose.py). 7.6 M pixels against 5 degrees of freedom: what agrees beyond that is the scene, the ray set-up
 # (focal length, sensor width, the uv arithmetic of RawFrame.glsl:428-429), the quad and sphere tests and 1 - min(t / 50, 0.9).
-S7_POSE = dict(pos=(4.5284, 2.15559, 24.68959), yaw=-97.49979, pitch=-0.51504, title_bar_rows=45)
+S7_POSE = dict(pos=(4.52691, 2.15391, 24.68646), yaw=-97.4972, pitch=-0.75073, title_bar_rows=45)   # the mouse grid has -97.5, -0.75
+SHOT_RENDER_SIZE, SHOT_LOST_ROWS = (3840, 2019), 45
 
 
 def app_camera(pos, yaw, pitch):
@@ -264,21 +269,21 @@ def s7_client_area():
 
 
 def check_s7(bytes_rendered):
-    """measured with the oracle: 99.30 % of the 7.6 M bytes identical, 99.989 % within one level (the rest are silhouette
-    pixels), 0.003 % of the image covered in one picture and not the other"""
+    """measured with the oracle: 99.45 % of the 7.6 M bytes identical, 99.998 % within one level, 0.001 % of the image
+    covered in one picture and not the other"""
     want = s7_client_area()
     d = np.abs(bytes_rendered.astype(np.int32) - want)
-    assert (d == 0).mean() >= 0.99 and (d <= 1).mean() >= 0.9995
-    assert ((want > 0) != (bytes_rendered > 0)).mean() <= 2e-4
+    assert (d == 0).mean() >= 0.992 and (d <= 1).mean() >= 0.9998
+    assert ((want > 0) != (bytes_rendered > 0)).mean() <= 1e-4
     both = (want > 0) & (bytes_rendered > 0)
-    assert abs((bytes_rendered.astype(np.int32) - want)[both].mean()) <= 0.05           # no brightness bias: measured +0.02 levels
+    assert abs((bytes_rendered.astype(np.int32) - want)[both].mean()) <= 0.06           # no brightness bias: measured +0.03 levels
 
 
 def test_reference_screenshot_zdepth(oracle_builtin):
-    """ZDepth at 3840x1974 from the fitted pose against the upstream screenshot, through the 8-bit attachments of the
+    """ZDepth at 3840x2019 from the fitted pose against the upstream screenshot (its 1974 rows), through the 8-bit attachments of the
     shipped application (a deterministic view: every frame is the same image, so one frame is the accumulation)"""
-    p = ko.default_params(width=3840, height=1974, mode=ko.MODE_Z, max_frames=0)
-    acc = ko.render_mean(oracle_builtin, s7_camera(), p, 1, unorm8=True)[..., 0]
+    p = ko.default_params(width=SHOT_RENDER_SIZE[0], height=SHOT_RENDER_SIZE[1], mode=ko.MODE_Z, max_frames=0)
+    acc = ko.render_mean(oracle_builtin, s7_camera(), p, 1, unorm8=True)[SHOT_LOST_ROWS:, :, 0]
     check_s7(np.rint(acc * 255.0).astype(np.int32))
 
 

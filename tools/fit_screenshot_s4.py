@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Recovers the camera of the upstream screenshot tests/golden/assets/S4.png (the reference application in its path-traced
 view) by fitting GPU renders to it, then renders the view as the shipped application would have shown it (30 frames through
-8-bit attachments, SAMPLES freeze, PostProcess clamp) at the window's 3840x1974 and compares byte for byte.
+8-bit attachments, SAMPLES freeze, PostProcess clamp) and compares byte for byte.
+
+The window: the picture is 3840x2019 = 45 rows of title bar + 1974 rows of image, but the application rendered 3840x2019
+(iResolution) and the capture, as tall as the client area but starting at the top of the title bar, lost the image's bottom
+45 rows: the per-pixel noise of the picture correlates with a render's only when the render's rows are shifted by 45 (the
+hash RNG is keyed by gl_FragCoord), at 53 sigma.
 
 Needs an MI355X (thousands of small renders). Stages: random search at 1/16 resolution, Nelder-Mead / Powell refinements at
 1/8 and 1/4 on blurred images (the low-resolution renders have their own noise: the hash RNG is keyed by pixel coordinates),
@@ -23,7 +28,8 @@ import klrender as kl  # noqa: E402
 DEG = 0.01745329252
 ASSETS = os.path.join(ROOT, "tests", "golden", "assets")
 SHOT = np.array(Image.open(os.path.join(ASSETS, "S4.png")).convert("RGB"))[45:][::-1].astype(np.float32)     # client area, rows bottom to top
-H, W = SHOT.shape[:2]
+H, W = SHOT.shape[:2]                         # what the picture shows: 1974 rows
+HF, OFF = 2019, 45                            # what the application rendered, and the rows the capture lost at the bottom
 BG = np.array(Image.open(os.path.join(ASSETS, "Background.png")))
 TX = np.load(os.path.join(ASSETS, "Texture_stb_rgb8.npz"))["rgb"]
 
@@ -44,10 +50,11 @@ def camera(p):
 class Level:
     def __init__(self, s, frames, sigma):
         self.s, self.w, self.h, self.frames, self.sigma = s, W // s, H // s, frames, sigma
+        self.off = int(round(OFF / s))
         # the screenshot averaged over s x s blocks (cropping the few rows that do not fill a block)
         t = SHOT[:self.h * s, :self.w * s].reshape(self.h, s, self.w, s, 3).mean(axis=(1, 3))
         self.target = self.blur(t)
-        self.r = kl.Renderer(self.w, self.h)
+        self.r = kl.Renderer(self.w, self.h + self.off)
         self.r.load_builtin_scene()
         self.r.upload_texture(kl.TEX_HDRI, BG)
         self.r.upload_texture(kl.TEX_ALBEDO, TX)
@@ -62,7 +69,7 @@ class Level:
     def render(self, p):
         self.r.set_camera(camera(p))
         self.r.render_frames(self.frames)
-        return self.r.resolve()[..., :3].astype(np.float32)
+        return self.r.resolve()[self.off:, :, :3].astype(np.float32)
 
     def cost(self, p):
         self.evals += 1
@@ -115,7 +122,7 @@ def block_stats(img, shot, b=32):
 
 def final(p, tag="s4"):
     """the view as shipped: 30 frames (the SAMPLES freeze), 8-bit attachments, at the window's own resolution"""
-    r = kl.Renderer(W, H)
+    r = kl.Renderer(W, HF)
     r.load_builtin_scene()
     r.upload_texture(kl.TEX_HDRI, BG)
     r.upload_texture(kl.TEX_ALBEDO, TX)
@@ -123,19 +130,26 @@ def final(p, tag="s4"):
     r.set_mode(kl.MODE_PT)
     r.set_camera(camera(p))
     r.render_frames(40)                     # frames 30..39 are frozen (max_frames = SAMPLES = 30): the picture stops changing
-    img = r.resolve()[..., :3].astype(np.int32)
+    img = r.resolve()[OFF:, :, :3].astype(np.int32)
     d = np.abs(img - SHOT.astype(np.int32)).max(axis=2)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     Image.fromarray(img[::-1].astype(np.uint8)).save(os.path.join(ROOT, "gpurun_out", tag + "_render.png"))
     Image.fromarray(np.clip(d[::-1] * 8, 0, 255).astype(np.uint8)).resize((W // 2, H // 2)).save(os.path.join(ROOT, "gpurun_out", tag + "_diff.png"))
     blocks = block_stats(img, SHOT)
+    hp = lambda a: a[..., 1].astype(np.float64) - ndimage.uniform_filter(a[..., 1].astype(np.float64), (9, 9))  # noqa: E731
+    ours, theirs = hp(img), hp(SHOT)
+    noise = {}
+    for name, (y0, y1, x0, x1) in {"top face": (1085, 1115, 2300, 2800), "floor": (1450, 1650, 1500, 2200), "textured wall": (1180, 1300, 1700, 1950)}.items():
+        a, b = ours[H - y1:H - y0, x0:x1].ravel(), theirs[H - y1:H - y0, x0:x1].ravel()
+        noise[name] = {"std_ours": round(float(a.std()), 3), "std_theirs": round(float(b.std()), 3), "correlation": round(float(np.corrcoef(a, b)[0, 1]), 4)}
+    blocks["noise"] = noise
     return {"blocks_32x32": blocks, "pose": np.round(p, 5).tolist(), "pixels_equal": float((d == 0).mean()), "within_1": float((d <= 1).mean()),
             "within_2": float((d <= 2).mean()), "within_8": float((d <= 8).mean()), "mae_levels": float(np.abs(img - SHOT).mean())}
 
 
 def refine_full(p):
     """last stage: the all-pixel mean absolute difference at the window's own resolution, as shipped"""
-    r = kl.Renderer(W, H)
+    r = kl.Renderer(W, HF)
     r.load_builtin_scene()
     r.upload_texture(kl.TEX_HDRI, BG)
     r.upload_texture(kl.TEX_ALBEDO, TX)
@@ -149,7 +163,7 @@ def refine_full(p):
         r.set_camera(camera(q))
         r.render_frames(30)
         n[0] += 1
-        c = float(np.abs(r.resolve()[..., :3].astype(np.int16) - shot).mean())
+        c = float(np.abs(r.resolve()[OFF:, :, :3].astype(np.int16) - shot).mean())
         if n[0] % 50 == 0:
             print("full", n[0], round(c, 4), np.round(q, 5).tolist(), round(time.time() - t0, 1), flush=True)
         return c
