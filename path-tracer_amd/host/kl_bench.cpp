@@ -5,6 +5,10 @@
 //   kl_bench --scene synth --blobs 1000 --tris-per-blob 1000 --w 1920 --h 1080 --frames 64 --bounces 8
 //   kl_bench --scene synth --builder gpu ...         (tree built on the GPU instead of the host cores)
 //   kl_bench --scene builtin --interactive-demo      (drives the GLSL_Renderer-shaped host class)
+//   kl_bench --scene builtin --mode pt --w 3840 --h 2019 --frames 40 --shipped --pos 10.59404 4.0598 29.49413 --yaw -112.42508 --pitch -0.8288
+//            --hdri Background.png --albedo Texture.png --out s4.png
+//       a view of the application as shipped: camera from position / yaw / pitch (Camera::f_compile), SAMPLES freeze at 30 frames,
+//       8-bit attachments (this line reproduces resources/Screenshots/S4.png, whose bottom 45 rows the capture lost)
 //   kl_bench --decode in.png out.raw                 (the host's image loader alone: writes the 8-bit pixels, prints "w h channels")
 //   kl_bench --scene synth --gpus 8 --partition tiles --w 3840 --h 2160 --frames 256 --bounces 8      (BASELINE configs[3])
 //   kl_bench --scene synth --gpus 8 --partition samples --blobs 9990 --spheres 10000 --w 3840 --h 2160 --frames 1024 --bounces 8
@@ -30,7 +34,8 @@ int main(int argc, char **argv) {
     uint32_t gpus = 0, band_rows = 8;
     int araw[3] = {0, 0, 0};
     uint32_t w = 1920, h = 1080, frames = 16, bounces = 0, blobs = 1000, tpb = 1000, spheres = 0, warmup = 1, device = 0, fif = 0;
-    bool demo = false;
+    bool demo = false, shipped = false, have_cam = false;
+    double cam_pos[3] = {0, 1, 5}, cam_yaw = -90, cam_pitch = 0;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -46,6 +51,10 @@ int main(int argc, char **argv) {
         else if (a == "--gpus") gpus = std::atoi(next()); else if (a == "--partition") partition = next();
         else if (a == "--exchange") exchange = next(); else if (a == "--devices") devlist = next(); else if (a == "--band-rows") band_rows = std::atoi(next());
         else if (a == "--interactive-demo") demo = true;
+        else if (a == "--shipped") shipped = true;
+        else if (a == "--pos") { for (int k = 0; k < 3; k++) cam_pos[k] = std::atof(next()); have_cam = true; }
+        else if (a == "--yaw") { cam_yaw = std::atof(next()); have_cam = true; }
+        else if (a == "--pitch") { cam_pitch = std::atof(next()); have_cam = true; }
         else if (a == "--decode") { decode_in = next(); decode_out = next(); }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -130,9 +139,12 @@ int main(int argc, char **argv) {
     CK(kl_create(&ctx, (int)device, w, h));
     kl_bvh_stats bs; std::memset(&bs, 0, sizeof bs);
     kl_params p; kl_default_params(&p);
-    p.max_frames = 0; if (bounces) p.max_bounces = bounces; p.frames_in_flight = fif;
+    if (!shipped) p.max_frames = 0;              // --shipped keeps #define SAMPLES 30: frames from the 30th on change nothing
+    if (bounces) p.max_bounces = bounces;
+    p.frames_in_flight = fif;
     p.bvh_builder = builder == "gpu" ? KL_BUILD_GPU_LBVH : KL_BUILD_HOST_SAH;      // read by the upload below
     CK(kl_set_params(ctx, &p));
+    if (shipped) CK(kl_set_accum_mode(ctx, KL_ACCUM_MEAN_UNORM8));      // the application's unsized GL_RGBA attachments (FBT.cpp:6)
     if (scene == "builtin") {
         CK(kl_load_builtin_scene(ctx));
     } else {
@@ -149,6 +161,14 @@ int main(int argc, char **argv) {
     if (!albedo.empty()) { if (!img.f_load(albedo)) { std::fprintf(stderr, "cannot read %s\n", albedo.c_str()); return 1; } CK(kl_upload_texture(ctx, KL_TEX_ALBEDO, img.data.data(), img.width, img.height, img.channels)); }
     if (!albedo_raw.empty()) { if (!img.f_load_raw(albedo_raw, araw[0], araw[1], araw[2])) { std::fprintf(stderr, "cannot read %s\n", albedo_raw.c_str()); return 1; } CK(kl_upload_texture(ctx, KL_TEX_ALBEDO, img.data.data(), img.width, img.height, img.channels)); }
     CK(kl_set_mode(ctx, mode == "ao" ? KL_MODE_AO : (mode == "z" ? KL_MODE_Z : KL_MODE_PT)));
+    if (have_cam) {
+        Camera cam;                                  // the reference's camera state: position + yaw / pitch (Camera.cpp:26-43)
+        cam.position = {cam_pos[0], cam_pos[1], cam_pos[2]};
+        cam.rotation = {cam_yaw, cam_pitch, 0.0};
+        cam.f_compile();
+        const kl_camera kc = cam.f_upload();
+        CK(kl_set_camera(ctx, &kc));
+    }
     for (uint32_t i = 0; i < warmup; i++) { CK(kl_reset(ctx)); CK(kl_render_frames(ctx, frames, 0)); }
     CK(kl_synchronize(ctx)); CK(kl_reset_counters(ctx)); CK(kl_reset(ctx));
     double t0 = now_s();

@@ -41,6 +41,22 @@ def test_host_session_follows_the_reference_reset_rules():
     assert second["mode"] == 2 and second["iFrame"] == 3 and abs(second["camera_x"] - 0.15) < 1e-9
 
 
+def test_kl_bench_reproduces_the_reference_screenshot(tmp_path):
+    """the whole host side in one line of kl_bench: its JPEG and PNG readers, Camera::f_compile from position / yaw / pitch, the
+    shipped accumulation (SAMPLES freeze, 8-bit attachments), kl_resolve and the PNG writer, against the upstream author's
+    path-traced screenshot (the picture shows the image's upper 1974 rows)"""
+    from PIL import Image
+    out = str(tmp_path / "s4.png")
+    subprocess.run([BENCH, "--scene", "builtin", "--mode", "pt", "--w", "3840", "--h", "2019", "--frames", "40", "--warmup", "0", "--shipped",
+                    "--pos", "10.59404", "4.0598", "29.49413", "--yaw", "-112.42508", "--pitch", "-0.8288",
+                    "--hdri", os.path.join(GOLDEN, "assets", "Background.png"), "--albedo", os.path.join(GOLDEN, "assets", "Texture.png"),
+                    "--out", out], check=True, capture_output=True, text=True, timeout=180)
+    got = np.array(Image.open(out).convert("RGB"))[:1974].astype(np.int32)               # PNG rows run top to bottom
+    shot = np.array(Image.open(os.path.join(GOLDEN, "assets", "S4.png")).convert("RGB"))[45:].astype(np.int32)
+    d = np.abs(got - shot).max(axis=2)
+    assert (d == 0).mean() >= 0.85 and (d <= 1).mean() >= 0.96 and (d <= 8).mean() >= 0.994 and np.abs(got - shot).mean() <= 0.2
+
+
 def test_kl_bench_drives_a_group_of_gpus(tmp_path):
     """the headless tool with --gpus: one process, kl_group_*, tiles over RCCL with the one GPU of the box, and three members
     sharing it through the copy exchange; same image mean as the single-context run"""
