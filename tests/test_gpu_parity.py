@@ -281,11 +281,6 @@ def test_reference_screenshot_zdepth_is_reproduced():
             check_s7(rgba8[SHOT_LOST_ROWS:, :, 0])
 
 
-# camera of the upstream screenshot S4.png (the path-traced view of the same session), fitted with GPU renders
-# (tools/fit_screenshot_s4.py): position, yaw (on the mouse grid: -90 - 299 x 0.075), pitch
-S4_POSE = (10.59404, 4.0598, 29.49413, -112.42508, -0.8288)
-
-
 def test_reference_screenshot_pathtraced_is_reproduced(textures):
     """The upstream author's screenshot of the path-traced view (tests/golden/assets/S4.png): the shipped pipeline (30 frames,
     SAMPLES freeze, 8-bit attachments, PostProcess clamp) at the window's 3840x2019 from the fitted pose, against the 1974
@@ -297,7 +292,7 @@ def test_reference_screenshot_pathtraced_is_reproduced(textures):
     spheres and paths of many near-mirror bounces, where the two GPUs' sin / cos / sqrt differ in the last bits)."""
     from PIL import Image
     from scipy import ndimage
-    from test_oracle_golden import S7_POSE, SHOT_LOST_ROWS, SHOT_RENDER_SIZE, app_camera
+    from test_oracle_golden import S4_POSE, S7_POSE, SHOT_LOST_ROWS, SHOT_RENDER_SIZE, app_camera
     shot = np.array(Image.open(os.path.join(GOLDEN, "assets", "S4.png")).convert("RGB"))[S7_POSE["title_bar_rows"]:][::-1].astype(np.int32)
     with make_renderer(*SHOT_RENDER_SIZE, textures) as r:             # max_frames stays 30 = #define SAMPLES
         r.set_accum_mode(kl.ACCUM_MEAN_UNORM8)
