@@ -5,7 +5,7 @@
 //   kl_bench --scene synth --blobs 1000 --tris-per-blob 1000 --w 1920 --h 1080 --frames 64 --bounces 8
 //   kl_bench --scene synth --builder gpu ...         (tree built on the GPU instead of the host cores)
 //   kl_bench --scene builtin --interactive-demo      (drives the GLSL_Renderer-shaped host class)
-//   kl_bench --scene builtin --mode pt --w 3840 --h 2019 --frames 40 --shipped --pos 10.59404 4.0598 29.49413 --yaw -112.42508 --pitch -0.8288
+//   kl_bench --scene builtin --mode pt --w 3840 --h 2019 --frames 40 --shipped --pos 10.58809 4.05715 29.47826 --yaw -112.42518 --pitch -0.82758
 //            --hdri Background.png --albedo Texture.png --out s4.png
 //       a view of the application as shipped: camera from position / yaw / pitch (Camera::f_compile), SAMPLES freeze at 30 frames,
 //       8-bit attachments (this line reproduces resources/Screenshots/S4.png, whose bottom 45 rows the capture lost)

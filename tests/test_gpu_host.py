@@ -48,13 +48,13 @@ def test_kl_bench_reproduces_the_reference_screenshot(tmp_path):
     from PIL import Image
     out = str(tmp_path / "s4.png")
     subprocess.run([BENCH, "--scene", "builtin", "--mode", "pt", "--w", "3840", "--h", "2019", "--frames", "40", "--warmup", "0", "--shipped",
-                    "--pos", "10.59404", "4.0598", "29.49413", "--yaw", "-112.42508", "--pitch", "-0.8288",
+                    "--pos", "10.58809", "4.05715", "29.47826", "--yaw", "-112.42518", "--pitch", "-0.82758",
                     "--hdri", os.path.join(GOLDEN, "assets", "Background.png"), "--albedo", os.path.join(GOLDEN, "assets", "Texture.png"),
                     "--out", out], check=True, capture_output=True, text=True, timeout=180)
     got = np.array(Image.open(out).convert("RGB"))[:1974].astype(np.int32)               # PNG rows run top to bottom
     shot = np.array(Image.open(os.path.join(GOLDEN, "assets", "S4.png")).convert("RGB"))[45:].astype(np.int32)
     d = np.abs(got - shot).max(axis=2)
-    assert (d == 0).mean() >= 0.85 and (d <= 1).mean() >= 0.96 and (d <= 8).mean() >= 0.994 and np.abs(got - shot).mean() <= 0.2
+    assert (d == 0).mean() >= 0.86 and (d <= 1).mean() >= 0.97 and (d <= 8).mean() >= 0.996 and np.abs(got - shot).mean() <= 0.16
 
 
 def test_kl_bench_drives_a_group_of_gpus(tmp_path):

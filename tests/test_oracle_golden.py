@@ -289,15 +289,15 @@ def test_reference_screenshot_zdepth(oracle_builtin):
 
 # camera of the upstream screenshot S4.png (the path-traced view of the same session), fitted with GPU renders
 # (tools/fit_screenshot_s4.py): position, yaw (on the mouse grid: -90 - 299 x 0.075), pitch (the grid has -0.825)
-S4_POSE = (10.59404, 4.0598, 29.49413, -112.42508, -0.8288)
+S4_POSE = (10.58809, 4.05715, 29.47826, -112.42518, -0.82758)
 
 
 def test_reference_screenshot_pathtraced_band(oracle_builtin):
     """64 rows of the upstream path-traced screenshot (through the floor, the upper spheres, the textured wall, the room's
     outside and the sky) from the oracle: 30 frames through the 8-bit attachments at the window's 3840x2019, rows rendered on
-    their own (a sample depends on nothing but its pixel and frame). The noisiest part of the picture; measured 61.6 % of
-    pixels identical in all three channels, 90.2 % within one level, 95.1 % within two, 97.8 % within eight, mean absolute
-    difference 0.61 levels (the whole picture, on the GPU: 86 % / 96.8 % / 98.6 % / 99.6 % / 0.17)."""
+    their own (a sample depends on nothing but its pixel and frame). The noisiest part of the picture; measured 62.3 % of
+    pixels identical in all three channels, 90.8 % within one level, 95.9 % within two, 98.5 % within eight, mean absolute
+    difference 0.52 levels (the whole picture, on the GPU: 86.6 % / 97.5 % / 99.1 % / 99.7 % / 0.14)."""
     from PIL import Image
     shot = np.array(Image.open(os.path.join(GOLDEN, "assets", "S4.png")).convert("RGB"))[S7_POSE["title_bar_rows"]:].astype(np.int32)
     r0, r1 = 1400, 1464                                   # picture rows, counted from the top of the image area
@@ -310,8 +310,8 @@ def test_reference_screenshot_pathtraced_band(oracle_builtin):
         ko.accumulate(acc, raw, f, camera_change=(f == 0), unorm8=True)
     band = np.rint(acc[y0:y1, :, :3] * 255.0).astype(np.int32)[::-1]
     d = np.abs(band - shot[r0:r1]).max(axis=2)
-    assert (d == 0).mean() >= 0.6 and (d <= 1).mean() >= 0.89 and (d <= 2).mean() >= 0.94 and (d <= 8).mean() >= 0.97
-    assert np.abs(band - shot[r0:r1]).mean() <= 0.7
+    assert (d == 0).mean() >= 0.61 and (d <= 1).mean() >= 0.9 and (d <= 2).mean() >= 0.95 and (d <= 8).mean() >= 0.98
+    assert np.abs(band - shot[r0:r1]).mean() <= 0.6
 
 
 def check_shipped_rgba8(key, acc, ref8):

@@ -10,7 +10,7 @@ hash RNG is keyed by gl_FragCoord), at 53 sigma.
 
 Needs an MI355X (thousands of small renders). Stages: random search at 1/16 resolution, Nelder-Mead / Powell refinements at
 1/8 and 1/4 on blurred images (the low-resolution renders have their own noise: the hash RNG is keyed by pixel coordinates),
-final render at full resolution. Prints one JSON line; writes the render and a difference picture under gpurun_out/."""
+refinement on the all-pixel difference at full resolution, final render. Prints one JSON line; writes the render and a difference picture under gpurun_out/."""
 import json
 import os
 import sys
@@ -103,6 +103,7 @@ def main():
             r = minimize(lv.cost, p, method="Nelder-Mead", options=dict(xatol=1e-6, fatol=1e-8, maxiter=2000, adaptive=True))
             p = r.x
         print("level", s, sigma, json.dumps(np.round(p, 5).tolist()), round(r.fun, 4), lv.evals, round(time.time() - t0, 1), flush=True)
+    p = refine_full(p)
     out = final(p)
     out["seconds"] = round(time.time() - t0, 1)
     print(json.dumps(out))
