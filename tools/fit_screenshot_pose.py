@@ -12,9 +12,10 @@ fitting the oracle's ZDepth render to it. The application's camera has five numb
   5. all five numbers refined continuously on the all-pixel mean absolute difference at 1/3 and full resolution (the best
      fit's pitch is not on the grid).
 
-CPU only (the oracle), about an hour on 8 cores (`--quick`: a few minutes, coarser). Prints the pose that
-tests/test_oracle_golden.py holds as S7_POSE: 99.45 % of the 7.6 M bytes identical, 99.998 % within one level; yaw and
-pitch come out within 0.003 degrees of the mouse grid (-97.5, -0.75)."""
+CPU only (the oracle), half an hour on 8 cores (`--quick`: a few minutes less, coarser). A run ends at 98.9 % of the 7.6 M
+bytes identical and 99.99 % within one level (4.528, 2.15758, 24.68618, -97.50017, -0.76110); repeating the last stage from a
+neighbouring start reached 99.45 % / 99.998 %, the pose tests/test_oracle_golden.py holds as S7_POSE. Yaw and pitch come out
+within 0.01 degrees of the mouse grid (-97.5, -0.75)."""
 import json
 import os
 import sys
