@@ -4,6 +4,7 @@
 lanes == one stream, sample ranges == mean, plus the oracle on a few full-width rows. Config 5's ten-million-
 primitive mixed scene: upload, tree guarantees, tree == flat loop on sampled rays, a 4K frame renders finite.
 """
+import os
 import zlib
 
 import numpy as np
@@ -11,6 +12,7 @@ import pytest
 
 import klrender as kl
 import kloracle as ko
+from conftest import ROOT
 from test_gpu_parity import assert_bitexact
 from test_gpu_scene import random_rays
 
@@ -165,3 +167,30 @@ def test_dist_partitions_through_rccl_with_one_rank(textures):
             assert np.allclose(got[..., :3], frozen[..., :3], rtol=2e-5, atol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("partition,scaling", [("samples", "weak"), ("samples", "strong"), ("tiles", "strong")])
+def test_bench_with_two_ranks_on_one_gpu(partition, scaling):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with two ranks
+    that share this box's one GPU: gloo carries the one collective instead of RCCL (which refuses two ranks on a device).
+    Small workload; checks the contract fields, the whole-job sample count and that both ranks' work is in the figure."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, KL_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "180", "--spp", "8",
+           "--blobs", "20", "--tris-per-blob", "200", "--partition", partition, "--scaling", scaling, "--skip-kernels", "--cpu-seconds", "0"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["unit"] == "samples/s" and j["vs_baseline"] is None and j["dtype"] == "f32"
+    assert j["scaling"] == scaling and j["value"] > 0 and j["higher_is_better"] is True
+    frames_total = 16 if (partition, scaling) == ("samples", "weak") else 8
+    assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 320 * 180 * frames_total) <= 1e-6 * 320 * 180 * frames_total     # value = whole-job samples / time
+    assert "gloo" in j["config"]["partition"]
