@@ -30,11 +30,12 @@ struct Huffman {
         int code = 0, index = 0;
         for (int len = 1; len <= 16; len++) {
             first_code[len] = code; first_index[len] = index;
-            for (int i = 0; i < counts[len - 1]; i++, code++, index++)
+            for (int i = 0; i < counts[len - 1]; i++, code++, index++) {
+                if (code >= (1 << len)) return false;        // over-subscribed: more codes of this length than there can be
                 if (len <= 9)
                     for (int pad = 0; pad < (1 << (9 - len)); pad++) fast[(code << (9 - len)) | pad] = (uint16_t)((len << 8) | symbols[index]);
+            }
             last_code[len] = code - 1;                       // < first_code when the length has no codes
-            if (code > (1 << len)) return false;             // over-subscribed
             code <<= 1;
         }
         present = true;

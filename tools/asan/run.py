@@ -93,6 +93,16 @@ def main():
                     for pos in rng.integers(8, min(len(dmg), 120), size=int(rng.integers(1, 4))):
                         dmg[int(pos)] = int(rng.integers(0, 256))
                     put("%s.d%d.png" % (key, k), bytes(dmg))
+            # Huffman tables that announce more codes of a length than exist: the file's first table (DC luminance) replaced by
+            # a well-formed segment whose counts over-subscribe the code space
+            jpg = cases["s420_45x31__jpeg"].tobytes()
+            at = jpg.find(b"\xff\xc4")
+            seg_len = struct.unpack(">H", jpg[at + 2:at + 4])[0]
+            for length, count in ((1, 200), (2, 9), (9, 255), (16, 255)):
+                counts = bytearray(16)
+                counts[length - 1] = count
+                body = bytes([0x00]) + bytes(counts) + bytes(range(count))
+                put("dht_%d_%d.jpg" % (length, count), jpg[:at] + b"\xff\xc4" + struct.pack(">H", 2 + len(body)) + body + jpg[at + 2 + seg_len:])
             put("huge.jpg", bytes.fromhex("ffd8ffc0000b08ffffffff01011100ffda0008010100003f00") + rng.bytes(64))
             put("soi.jpg", b"\xff\xd8\xff")
             import zlib
