@@ -90,7 +90,7 @@ def cpu_baseline(scene_arrays, textures, width, height, bounces, budget_s):
     what = "frames 0..%d (all rows)" % (nframes - 1)
     return {"value": cn.paths / dt, "unit": "samples/s", "cores": threads, "kind": "port", "nproc": os.cpu_count(), "affinity_cores": avail,
             "mrays_per_s": cn.rays / dt / 1e6, "seconds": round(dt, 2),
-            "sample": "%s of the same %dx%d %d-bounce workload (%d paths, %d rays), oracle C port with its own median-split BVH, %d OpenMP threads"
+            "sample": "%s of the same %dx%d %d-bounce workload (%d paths, %d rays), oracle C port with its own median-split BVH (NOT the product's SAH tree: the GPU/CPU ratio is not like for like), %d OpenMP threads"
                       % (what, width, height, bounces, cn.paths, cn.rays, threads)}
 
 

@@ -222,6 +222,9 @@ KL_API kl_status kl_synth_scene_fill(const kl_synth_params *sp, kl_sphere *spher
  *    first_frame = KL_CONTINUE continues from the context's frame counter -- */
 KL_API kl_status kl_render_frames(kl_ctx *ctx, uint32_t n, uint32_t first_frame);
 KL_API kl_status kl_synchronize(kl_ctx *ctx);
+/* the HIP stream (a hipStream_t, handed over as void*) on which the context queues its work, so that a caller can order its
+ * own streams against it with events. No reference counterpart (the reference has one GL context and no streams). */
+KL_API kl_status kl_get_stream(kl_ctx *ctx, void **hip_stream);
 
 /* -- accumulation checkpoint (no reference counterpart: the reference restarts from iFrame = 0): writes / reads
  *    {image size and shard, frame counter, view mode, camera, parameters, accumulation, last raw frame}. After a
@@ -247,14 +250,19 @@ KL_API kl_status kl_trace_rays(kl_ctx *ctx, const float *o, const float *d, uint
                                float *t, uint32_t *prim, float *uv);
 
 /* One entry point that allocates nothing. It has no counterpart in the reference; it is kl_trace_rays for callers that
- * cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * cannot allocate device memory: tight serving loops, harnesses that forbid hipMalloc, code whose surrounding region
+ * must stay free of allocation calls.
  * All pointers are DEVICE pointers on the context's device (o, d: n x 3 floats; t: n; prim: n; uv: n x 2 floats).
  * The queue entries, counters and traversal stack spill that kl_trace_rays allocates per call live in a fixed
  * device array of the library instead (about 33 MB per GPU, held until the process ends), hence the limit:
- * n <= KL_NOALLOC_MAX_RAYS, else KL_E_LIMIT. The work is queued on the context's stream and the call returns without
- * waiting (kl_synchronize waits). Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two
- * contexts, two threads) race; calls on one context are ordered by its stream. Same hits as kl_trace_rays, bit for
- * bit; rays traced here are not tallied by kl_get_counters. */
+ * n <= KL_NOALLOC_MAX_RAYS, else KL_E_LIMIT.
+ * Ordering: the kernels are queued on the CONTEXT's stream (kl_get_stream), which is a non-blocking stream: it is ordered
+ * neither with the null stream nor with the caller's streams. The inputs must therefore be complete before the call (the
+ * caller synchronises its own stream or device, or makes the context's stream wait on an event of its own), and the outputs
+ * are valid after kl_synchronize (or after an event the caller records on the context's stream). The call returns without
+ * waiting. Every call on a GPU uses that GPU's one array: the library orders calls that reach one GPU through different
+ * contexts or threads one after the other (an event wait between them, no allocation), so they do not race, but they do not
+ * overlap either. Same hits as kl_trace_rays, bit for bit; rays traced here are not tallied by kl_get_counters. */
 #define KL_NOALLOC_MAX_RAYS 262144u
 KL_API kl_status kl_trace_rays_noalloc(kl_ctx *ctx, const float *o_dev, const float *d_dev, uint32_t n,
                                        float *t_dev, uint32_t *prim_dev, float *uv_dev);
@@ -296,12 +304,15 @@ KL_API kl_status kl_group_set_params(kl_group *g, const kl_params *p);
 KL_API kl_status kl_group_set_camera(kl_group *g, const kl_camera *cam);
 KL_API kl_status kl_group_set_mode(kl_group *g, uint32_t mode);
 KL_API kl_status kl_group_reset(kl_group *g);
-/* n frames from first_frame (KL_CONTINUE: after the last ones), queued on every member; returns without waiting */
+/* n frames from first_frame (KL_CONTINUE: after the last ones), queued on every member; returns without waiting. If a member
+ * fails, the members before it already hold frames the others lack: the group then answers KL_E_STATE to further render and
+ * gather calls until kl_group_reset. */
 KL_API kl_status kl_group_render_frames(kl_group *g, uint32_t n, uint32_t first_frame);
 /* the exchange: afterwards every member holds the whole image (sample ranges: the mean over the frames rendered since the
  * last reset) on its device; member 0's copy goes to rgba (height x width x 4 floats, row 0 = bottom) unless that is NULL */
 KL_API kl_status kl_group_gather(kl_group *g, float *rgba, size_t bytes);
 KL_API kl_status kl_group_image_device(kl_group *g, uint32_t rank, const float **rgba_device);
+/* text of the group's last error; g = NULL: why the last kl_group_create on the calling thread failed */
 KL_API const char *kl_group_last_error(kl_group *g);
 
 KL_API const char *kl_status_string(kl_status s);

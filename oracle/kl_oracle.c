@@ -803,7 +803,8 @@ void ko_accumulate_unorm8(float *acc, const float *raw, size_t npix, uint32_t fr
 }
 
 /* PostProcess.glsl:34-39. CLAMP is the value that line 38 hands to an 8-bit
- * UNORM backbuffer; ACES evaluates the overwritten lines 35-37. */
+ * UNORM backbuffer; ACES evaluates the overwritten lines 35-37. The backbuffer keeps a value the way the RGBA8
+ * attachments do (unorm8 above, the rule pinned by the reference run): clamp, rint(x * 255), ties to even. */
 void ko_resolve(const float *acc, uint8_t *rgba8, size_t npix, int tonemap) {
     for (size_t i = 0; i < npix; i++) {
         float c[4] = { acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3] };
@@ -817,10 +818,6 @@ void ko_resolve(const float *acc, uint8_t *rgba8, size_t npix, int tonemap) {
             for (int k = 0; k < 3; k++) c[k] = (v[k] * (2.51f * v[k] + 0.03f)) / (v[k] * (2.43f * v[k] + 0.59f) + 0.14f);
             c[3] = 1.0f;
         }
-        for (int k = 0; k < 4; k++) {
-            float f = c[k];
-            f = !(f >= 0.0f) ? 0.0f : (f > 1.0f ? 1.0f : f);
-            rgba8[4 * i + k] = (uint8_t)(f * 255.0f + 0.5f);
-        }
+        for (int k = 0; k < 4; k++) rgba8[4 * i + k] = (uint8_t)rintf(unorm8(c[k]) * 255.0f);
     }
 }

@@ -910,6 +910,12 @@ kl_status kl_synchronize(kl_ctx *c) {
     return KL_OK;
 }
 
+kl_status kl_get_stream(kl_ctx *c, void **hip_stream) {
+    if (!c || !hip_stream) return KL_E_INVALID;
+    *hip_stream = (void *)c->stream;
+    return KL_OK;
+}
+
 static kl_status read_buf(kl_ctx *c, const DevBuf<float4> &b, float *rgba, size_t bytes) {
     if (!c || !rgba) return fail(c, KL_E_INVALID, "null output");
     if (!b.p || b.n != c->npl) return fail(c, KL_E_STATE, "nothing rendered yet");

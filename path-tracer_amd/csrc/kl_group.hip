@@ -91,12 +91,24 @@ struct kl_group {
     std::vector<Member> m;
     uint32_t next_frame = 0;          // sample ranges: the frame after the last one handed out
     uint64_t frames_given = 0;        // ... and how many were handed out since the last reset (the divisor of the mean)
+    bool broken = false;              // a render call failed part-way: some members hold frames the others do not, until kl_group_reset
     std::string err;
 };
 
 namespace {
 
+// why the last kl_group_create on this thread failed (there is no group yet to hold the text); kl_group_last_error(NULL) returns it
+thread_local std::string t_create_err;
+
 kl_status gfail(kl_group *g, kl_status s, const std::string &msg) { if (g) { try { g->err = msg; } catch (...) {} } return s; }
+// No exception crosses the C ABI: the std::vector / std::string allocations of an entry point's body (the error
+// macros below build strings too) become a status here.
+template <typename F> kl_status gguarded(kl_group *g, F body) noexcept {
+    try { return body(); }
+    catch (const std::bad_alloc &) { if (g) { try { g->err = "host memory exhausted"; } catch (...) {} } return KL_E_NOMEM; }
+    catch (const std::exception &e) { if (g) { try { g->err = e.what(); } catch (...) {} } return KL_E_INVALID; }
+    catch (...) { return KL_E_INVALID; }
+}
 #define KLG_HIP(g, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return gfail(g, e_ == hipErrorOutOfMemory ? KL_E_NOMEM : KL_E_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 #define KLG_NCCL(g, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return gfail(g, KL_E_DEVICE, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); } while (0)
 #define KLG_CTX(g, k, call) do { kl_status s_ = (call); if (s_ != KL_OK) return gfail(g, s_, std::string(#call) + " on member " + std::to_string(k) + ": " + kl_last_error((g)->m[k].ctx)); } while (0)
@@ -129,9 +141,10 @@ kl_status kl_group_create(kl_group **out, const int32_t *devices, uint32_t n, ui
     if (!out) return KL_E_INVALID;
     *out = nullptr;
     const uint32_t exchange = split & KL_EXCHANGE_COPY, how = split & ~(uint32_t)KL_EXCHANGE_COPY;
-    if (!devices || n == 0 || n > 64 || how > KL_SPLIT_SAMPLES || band_rows == 0) return KL_E_INVALID;
+    auto why_failed = [](const std::string &msg) { try { t_create_err = msg; } catch (...) {} };
+    if (!devices || n == 0 || n > 64 || how > KL_SPLIT_SAMPLES || band_rows == 0) { why_failed("bad argument"); return KL_E_INVALID; }
     kl_group *g = new (std::nothrow) kl_group();
-    if (!g) return KL_E_NOMEM;
+    if (!g) { why_failed("host memory exhausted"); return KL_E_NOMEM; }
     try {
         g->n = n; g->split = how; g->exchange = exchange; g->width = width; g->height = height; g->band_rows = band_rows;
         g->m.resize(n);
@@ -143,7 +156,10 @@ kl_status kl_group_create(kl_group **out, const int32_t *devices, uint32_t n, ui
             kl_status s = kl_create(&mb.ctx, devices[r], width, height);
             if (s == KL_OK && how == KL_SPLIT_TILES) s = kl_set_shard(mb.ctx, r, n, band_rows);
             if (s == KL_OK && how == KL_SPLIT_SAMPLES) s = kl_set_accum_mode(mb.ctx, KL_ACCUM_SUM);
-            if (s != KL_OK) { release(g); return s; }
+            if (s != KL_OK) {
+                why_failed("member " + std::to_string(r) + " (device " + std::to_string(devices[r]) + "): " + (mb.ctx ? kl_last_error(mb.ctx) : kl_status_string(s)));
+                release(g); return s;
+            }
             const size_t full = (size_t)width * height, block = (size_t)g->pad_rows * width;
             hipError_t e = hipSetDevice(mb.device);
             if (e == hipSuccess) e = hipMalloc((void **)&mb.full, full * sizeof(float4));
@@ -152,16 +168,20 @@ kl_status kl_group_create(kl_group **out, const int32_t *devices, uint32_t n, ui
                 e = hipMalloc((void **)&mb.stage, block * sizeof(float4));
                 if (e == hipSuccess) e = hipMemset(mb.stage, 0, block * sizeof(float4));
             }
-            if (e != hipSuccess) { release(g); return e == hipErrorOutOfMemory ? KL_E_NOMEM : KL_E_DEVICE; }
+            if (e != hipSuccess) {
+                why_failed("exchange buffers of member " + std::to_string(r) + ": " + hipGetErrorString(e));
+                release(g); return e == hipErrorOutOfMemory ? KL_E_NOMEM : KL_E_DEVICE;
+            }
         }
         if (!exchange) {
             std::string why;
-            if (!g_rccl.load(why)) { release(g); return KL_E_DEVICE; }
+            if (!g_rccl.load(why)) { why_failed(why); release(g); return KL_E_DEVICE; }
             std::vector<ncclComm_t> comms(n, nullptr);
-            if (g_rccl.CommInitAll(comms.data(), (int)n, devs.data()) != ncclSuccess) { release(g); return KL_E_DEVICE; }
+            const ncclResult_t cr = g_rccl.CommInitAll(comms.data(), (int)n, devs.data());
+            if (cr != ncclSuccess) { why_failed(std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(cr)); release(g); return KL_E_DEVICE; }
             for (uint32_t r = 0; r < n; r++) g->m[r].comm = comms[r];
         }
-    } catch (...) { release(g); return KL_E_NOMEM; }
+    } catch (...) { why_failed("host memory exhausted"); release(g); return KL_E_NOMEM; }
     *out = g;
     return KL_OK;
 }
@@ -177,54 +197,81 @@ kl_status kl_group_member(kl_group *g, uint32_t rank, kl_ctx **ctx) {
     *ctx = g->m[rank].ctx;
     return KL_OK;
 }
-const char *kl_group_last_error(kl_group *g) { return g ? g->err.c_str() : "null group"; }
+// g = NULL: why the last kl_group_create on the calling thread failed
+const char *kl_group_last_error(kl_group *g) { return g ? g->err.c_str() : t_create_err.c_str(); }
 
 // ---- the same input to every member
-kl_status kl_group_upload_scene(kl_group *g, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
+static kl_status kl_group_upload_scene_body(kl_group *g, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
                                 const kl_material *mt, uint32_t nm) {
     if (!g) return KL_E_INVALID;
     for (uint32_t k = 0; k < g->n; k++) KLG_CTX(g, k, kl_upload_scene(g->m[k].ctx, s, ns, q, nq, t, nt, mt, nm));
     return kl_group_reset(g);
 }
-kl_status kl_group_load_builtin_scene(kl_group *g) {
+kl_status kl_group_upload_scene(kl_group *g, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
+                                const kl_material *mt, uint32_t nm) {
+    return gguarded(g, [&]() { return kl_group_upload_scene_body(g, s, ns, q, nq, t, nt, mt, nm); });
+}
+static kl_status kl_group_load_builtin_scene_body(kl_group *g) {
     if (!g) return KL_E_INVALID;
     for (uint32_t k = 0; k < g->n; k++) KLG_CTX(g, k, kl_load_builtin_scene(g->m[k].ctx));
     return kl_group_reset(g);
 }
-kl_status kl_group_upload_texture(kl_group *g, uint32_t which, const uint8_t *px, uint32_t w, uint32_t h, uint32_t ch) {
+kl_status kl_group_load_builtin_scene(kl_group *g) {
+    return gguarded(g, [&]() { return kl_group_load_builtin_scene_body(g); });
+}
+static kl_status kl_group_upload_texture_body(kl_group *g, uint32_t which, const uint8_t *px, uint32_t w, uint32_t h, uint32_t ch) {
     if (!g) return KL_E_INVALID;
     for (uint32_t k = 0; k < g->n; k++) KLG_CTX(g, k, kl_upload_texture(g->m[k].ctx, which, px, w, h, ch));
     return KL_OK;
 }
-kl_status kl_group_set_params(kl_group *g, const kl_params *p) {
+kl_status kl_group_upload_texture(kl_group *g, uint32_t which, const uint8_t *px, uint32_t w, uint32_t h, uint32_t ch) {
+    return gguarded(g, [&]() { return kl_group_upload_texture_body(g, which, px, w, h, ch); });
+}
+static kl_status kl_group_set_params_body(kl_group *g, const kl_params *p) {
     if (!g) return KL_E_INVALID;
     for (uint32_t k = 0; k < g->n; k++) KLG_CTX(g, k, kl_set_params(g->m[k].ctx, p));
     return KL_OK;
 }
-kl_status kl_group_set_camera(kl_group *g, const kl_camera *cam) {
+kl_status kl_group_set_params(kl_group *g, const kl_params *p) {
+    return gguarded(g, [&]() { return kl_group_set_params_body(g, p); });
+}
+static kl_status kl_group_set_camera_body(kl_group *g, const kl_camera *cam) {
     if (!g) return KL_E_INVALID;
     for (uint32_t k = 0; k < g->n; k++) KLG_CTX(g, k, kl_set_camera(g->m[k].ctx, cam));
     return kl_group_reset(g);
 }
-kl_status kl_group_set_mode(kl_group *g, uint32_t mode) {
+kl_status kl_group_set_camera(kl_group *g, const kl_camera *cam) {
+    return gguarded(g, [&]() { return kl_group_set_camera_body(g, cam); });
+}
+static kl_status kl_group_set_mode_body(kl_group *g, uint32_t mode) {
     if (!g) return KL_E_INVALID;
     for (uint32_t k = 0; k < g->n; k++) KLG_CTX(g, k, kl_set_mode(g->m[k].ctx, mode));
     return kl_group_reset(g);
 }
-kl_status kl_group_reset(kl_group *g) {
+kl_status kl_group_set_mode(kl_group *g, uint32_t mode) {
+    return gguarded(g, [&]() { return kl_group_set_mode_body(g, mode); });
+}
+static kl_status kl_group_reset_body(kl_group *g) {
     if (!g) return KL_E_INVALID;
     for (uint32_t k = 0; k < g->n; k++) KLG_CTX(g, k, kl_reset(g->m[k].ctx));
-    g->next_frame = 0; g->frames_given = 0;
+    g->next_frame = 0; g->frames_given = 0; g->broken = false;
     return KL_OK;
+}
+kl_status kl_group_reset(kl_group *g) {
+    return gguarded(g, [&]() { return kl_group_reset_body(g); });
 }
 
 // Image tiles: every member renders the n frames over its row bands. Sample ranges: member r renders frames
 // [first + n*r/N, first + n*(r+1)/N) over the whole image as a sum. Work is queued on every member before any is waited for.
-kl_status kl_group_render_frames(kl_group *g, uint32_t n, uint32_t first_frame) {
+static kl_status kl_group_render_frames_body(kl_group *g, uint32_t n, uint32_t first_frame) {
     if (!g) return KL_E_INVALID;
     if (n == 0) return KL_OK;
+    if (g->broken) return gfail(g, KL_E_STATE, "an earlier kl_group_render_frames failed part-way; kl_group_reset first");
     const uint32_t first = first_frame == KL_CONTINUE ? g->next_frame : first_frame;
     if ((uint64_t)first + n > 0xFFFFFFFEull) return gfail(g, KL_E_LIMIT, "frame index overflow");
+    // A member that fails leaves the members before it with frames the others do not have (their sums and frame counters have
+    // moved on): the group then refuses to render or gather until kl_group_reset brings every member back to frame 0.
+    g->broken = true;
     for (uint32_t k = 0; k < g->n; k++) {
         if (g->split == KL_SPLIT_TILES) {
             KLG_CTX(g, k, kl_render_frames(g->m[k].ctx, n, first));
@@ -233,6 +280,7 @@ kl_status kl_group_render_frames(kl_group *g, uint32_t n, uint32_t first_frame) 
             if (hi > lo) KLG_CTX(g, k, kl_render_frames(g->m[k].ctx, hi - lo, lo));
         }
     }
+    g->broken = false;
     // frames that add to the sum: those before the SAMPLES freeze (RawFrame.glsl:426), which every member applies alike
     CtxView v;
     KLG_CTX(g, 0, ctx_view(g->m[0].ctx, &v));
@@ -241,13 +289,17 @@ kl_status kl_group_render_frames(kl_group *g, uint32_t n, uint32_t first_frame) 
     g->next_frame = first + n;
     return KL_OK;
 }
+kl_status kl_group_render_frames(kl_group *g, uint32_t n, uint32_t first_frame) {
+    return gguarded(g, [&]() { return kl_group_render_frames_body(g, n, first_frame); });
+}
 
 // The exchange step: afterwards every member holds the whole image (for sample ranges: the mean over all frames given out
 // since the last reset) in a buffer of its own; member 0's is copied to rgba if that is not null. Waits for completion.
-kl_status kl_group_gather(kl_group *g, float *rgba, size_t bytes) {
+static kl_status kl_group_gather_body(kl_group *g, float *rgba, size_t bytes) {
     if (!g) return KL_E_INVALID;
     const size_t full = (size_t)g->width * g->height, block = (size_t)g->pad_rows * g->width;
     if (rgba && bytes != full * sizeof(float4)) return gfail(g, KL_E_INVALID, "output must be height x width x 16 bytes");
+    if (g->broken) return gfail(g, KL_E_STATE, "an earlier kl_group_render_frames failed part-way; kl_group_reset first");
     std::vector<CtxView> v(g->n);
     for (uint32_t k = 0; k < g->n; k++) KLG_CTX(g, k, ctx_view(g->m[k].ctx, &v[k]));
     // what each member contributes: its accumulation buffer as it stands, or (tiles, ragged last band) padded to the block size
@@ -302,6 +354,9 @@ kl_status kl_group_gather(kl_group *g, float *rgba, size_t bytes) {
         KLG_HIP(g, hipStreamSynchronize(v[k].stream));
     }
     return KL_OK;
+}
+kl_status kl_group_gather(kl_group *g, float *rgba, size_t bytes) {
+    return gguarded(g, [&]() { return kl_group_gather_body(g, rgba, bytes); });
 }
 
 kl_status kl_group_image_device(kl_group *g, uint32_t rank, const float **rgba_device) {

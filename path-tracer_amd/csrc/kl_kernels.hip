@@ -16,6 +16,8 @@
 //
 // Arithmetic that restates the reference shader (resources/Shaders/RawFrame.glsl,
 // cited as RF:line) keeps its operation order and is compiled unfused.
+#include <mutex>
+
 #include "kl_kernels.hpp"
 #include "kl_math.hpp"
 
@@ -956,14 +958,9 @@ __global__ __launch_bounds__(256) void k_resolve(const float4 *acc, uchar4 *out,
             c.z = (b * (2.51f * b + 0.03f)) / (b * (2.43f * b + 0.59f) + 0.14f);
             c.w = 1.0f;
         }
-        float v[4] = {c.x, c.y, c.z, c.w};
-        unsigned char o[4];
-        for (int k = 0; k < 4; k++) {
-            float q = v[k];
-            q = !(q >= 0.0f) ? 0.0f : (q > 1.0f ? 1.0f : q);
-            o[k] = (unsigned char)(q * 255.0f + 0.5f);
-        }
-        out[i] = make_uchar4(o[0], o[1], o[2], o[3]);
+        // the 8-bit backbuffer keeps what an RGBA8 attachment keeps (unorm8 above: clamp, round to nearest, ties to even)
+        out[i] = make_uchar4((unsigned char)rintf(unorm8(c.x) * 255.0f), (unsigned char)rintf(unorm8(c.y) * 255.0f),
+                             (unsigned char)rintf(unorm8(c.z) * 255.0f), (unsigned char)rintf(unorm8(c.w) * 255.0f));
     }
 }
 
@@ -1070,6 +1067,13 @@ static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
 
 constexpr int NOALLOC_MAX_DEVICES = 64;
 static unsigned char *g_scratch_ptr[NOALLOC_MAX_DEVICES];      // device address of `scratch` on each GPU, set once per device
+// Calls on one GPU share that GPU's array. Each call records an event behind its last launch; a call that arrives on another
+// stream than the one before it first makes its stream wait for that event, so calls from different contexts or threads run
+// one after the other instead of racing on the array (no allocation: the event is made once per device, at set-up).
+static hipEvent_t g_scratch_done[NOALLOC_MAX_DEVICES];
+static hipStream_t g_scratch_last_stream[NOALLOC_MAX_DEVICES];
+static bool g_scratch_used[NOALLOC_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
 
 size_t noalloc_scratch_bytes() { return NOALLOC_BYTES; }
 
@@ -1078,10 +1082,16 @@ size_t noalloc_scratch_bytes() { return NOALLOC_BYTES; }
 hipError_t noalloc_init(int device) {
     if (device < 0 || device >= NOALLOC_MAX_DEVICES) return hipErrorInvalidDevice;
     if (__atomic_load_n(&g_scratch_ptr[device], __ATOMIC_ACQUIRE)) return hipSuccess;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return hipSuccess;
     unsigned char *ptr = nullptr;
     hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess) return e;
     if (!ptr) return hipErrorInvalidSymbol;
+    if (!g_scratch_done[device]) {
+        e = hipEventCreateWithFlags(&g_scratch_done[device], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
     __atomic_store_n(&g_scratch_ptr[device], ptr, __ATOMIC_RELEASE);
     return hipSuccess;
 }
@@ -1107,6 +1117,12 @@ hipError_t launch_trace_noalloc(hipStream_t s, int device, const LaunchCfg &lc, 
     if (device < 0 || device >= NOALLOC_MAX_DEVICES || n == 0 || n > KL_NOALLOC_MAX_RAYS || f.nseg != 1u || f.segcap < n) return hipErrorInvalidValue;
     unsigned char *base = __atomic_load_n(&g_scratch_ptr[device], __ATOMIC_ACQUIRE);
     if (!base) return hipErrorNotInitialized;
+    // one call at a time on this GPU's array: queue behind the previous call if it went to another stream
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_used[device] && g_scratch_last_stream[device] != s) {
+        const hipError_t we = hipStreamWaitEvent(s, g_scratch_done[device], 0);
+        if (we != hipSuccess) return we;
+    }
     RayQueue q = { (float4 *)(base + NOALLOC_OD), (float4 *)(base + NOALLOC_DT), nullptr, (float2 *)(base + NOALLOC_UV) };
     uint32_t *ctl = (uint32_t *)(base + NOALLOC_CTL);
     Counters *cn = (Counters *)(base + NOALLOC_CN);
@@ -1117,7 +1133,10 @@ hipError_t launch_trace_noalloc(hipStream_t s, int device, const LaunchCfg &lc, 
     small.cus = NOALLOC_BLOCKS; small.isect_blocks_per_cu = 1;
     launch_intersect(s, small, sc, f, q, ctl, ctl + CTR_STRIDE, cn, ovf, bvh, 0, n);
     launch_unpack_hits(s, sc, q, n, t, prim, uv);
-    return hipGetLastError();
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return le;
+    g_scratch_used[device] = true; g_scratch_last_stream[device] = s;
+    return hipEventRecord(g_scratch_done[device], s);
 }
 
 }  // namespace kl

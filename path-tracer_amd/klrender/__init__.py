@@ -104,6 +104,7 @@ SIGNATURES = {
     "kl_reset_counters": (C.c_int32, [_P]),
     "kl_get_timing": (C.c_int32, [_P, C.POINTER(Timing)]),
     "kl_trace_rays": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _P]),
+    "kl_get_stream": (C.c_int32, [_P, _P]),
     "kl_trace_rays_noalloc": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _P]),
     "kl_set_shard": (C.c_int32, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "kl_get_local_rows": (C.c_int32, [_P, C.POINTER(C.c_uint32)]),
@@ -374,6 +375,12 @@ class Renderer:
         uv = np.empty((n, 2), dtype=np.float32)
         self._ck(lib().kl_trace_rays(self._h, _ptr(o), _ptr(d), n, _ptr(t), _ptr(prim), _ptr(uv)), "kl_trace_rays")
         return t, prim, uv
+
+    def stream(self):
+        """the context's HIP stream as an integer handle (kl_get_stream)"""
+        h = C.c_void_p()
+        self._ck(lib().kl_get_stream(self._h, C.byref(h)), "kl_get_stream")
+        return h.value or 0
 
     def trace_rays_noalloc(self, o_dev, d_dev, n, t_dev, prim_dev, uv_dev):
         """kl_trace_rays_noalloc: DEVICE pointers (integers) in and out, at most NOALLOC_MAX_RAYS rays, asynchronous"""

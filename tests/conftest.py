@@ -53,3 +53,11 @@ def mae_clamped(a, ref):
     """mean absolute error of what reaches the screen: PostProcess.glsl:38 writes the
     accumulation texel to a UNORM backbuffer, i.e. clamp(x, 0, 1)"""
     return float(np.mean(np.abs(np.clip(a, 0, 1).astype(np.float64) - np.clip(ref, 0, 1).astype(np.float64))))
+
+
+def free_port():
+    """a TCP port nobody listens on right now (the kernel picks it), for torch.distributed rendezvous on 127.0.0.1"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

@@ -12,7 +12,7 @@ import pytest
 
 import klrender as kl
 import kloracle as ko
-from conftest import ROOT
+from conftest import ROOT, free_port
 from test_gpu_parity import assert_bitexact
 from test_gpu_scene import random_rays
 
@@ -142,7 +142,7 @@ def test_dist_partitions_through_rccl_with_one_rank(textures):
     from klrender import dist as kdist
     scene = kl.synth_scene(blobs=12, tris_per_blob=200, analytic_spheres=10, seed=5)
     w, h, n = 96, 54, 6
-    port = 29600 + os.getpid() % 1000
+    port = free_port()
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         with kl.Renderer(w, h) as r:
@@ -175,12 +175,9 @@ def test_bench_with_two_ranks_on_one_gpu(partition, scaling):
     that share this box's one GPU: gloo carries the one collective instead of RCCL (which refuses two ranks on a device).
     Small workload; checks the contract fields, the whole-job sample count and that both ranks' work is in the figure."""
     import json
-    import socket
     import subprocess
     import sys
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = free_port()
     env = dict(os.environ, KL_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "180", "--spp", "8",

@@ -57,3 +57,29 @@ def test_noalloc_trace_equals_trace_rays_on_two_calls_in_a_row():
         _same(_noalloc(r, torch, o, d), r.trace_rays(o, d), "flat loop")
         o, d = random_rays(77, 26)
         _same(_noalloc(r, torch, o, d), r.trace_rays(o, d), "flat loop, smaller")
+
+
+def test_two_contexts_on_one_gpu_do_not_race_on_the_shared_array():
+    """Two contexts (two streams) on one GPU queue calls back to back without waiting in between: the library orders them
+    one after the other on that GPU's one array, so both return the hits of kl_trace_rays."""
+    import torch
+    s, q, t, m = kl.synth_scene(blobs=24, tris_per_blob=160, analytic_spheres=40, seed=3)
+    with kl.Renderer(8, 8) as a, kl.Renderer(8, 8) as b:
+        assert a.stream() != b.stream() and a.stream() != 0
+        for r in (a, b):
+            r.update_params(accel=kl.ACCEL_BVH)
+            r.upload_scene(s, q, t, m)
+        dev = torch.device("cuda", a.device)
+        rays = [random_rays(150000, 31), random_rays(9000, 32), random_rays(120000, 33), random_rays(500, 34)]
+        want = [a.trace_rays(o, d) for o, d in rays]
+        bufs = []
+        for o, d in rays:
+            n = len(o)
+            bufs.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), torch.full((n,), -7.0, dtype=torch.float32, device=dev),
+                         torch.full((n,), 12345, dtype=torch.int32, device=dev), torch.full((n, 2), -7.0, dtype=torch.float32, device=dev)))
+        torch.cuda.synchronize(dev)                               # inputs complete before the calls, as the header asks
+        for k, (od, dd, tt, pp, uu) in enumerate(bufs):           # a, b, a, b: no wait between the calls
+            (a if k % 2 == 0 else b).trace_rays_noalloc(od.data_ptr(), dd.data_ptr(), len(od), tt.data_ptr(), pp.data_ptr(), uu.data_ptr())
+        a.synchronize(); b.synchronize()
+        for k, (od, dd, tt, pp, uu) in enumerate(bufs):
+            _same((tt.cpu().numpy(), pp.cpu().numpy().view(np.uint32), uu.cpu().numpy()), want[k], "overlapped call %d" % k)
