@@ -212,6 +212,17 @@ KL_API void kl_free(void *p);
 KL_API kl_status kl_refit_scene(kl_ctx *ctx, const kl_sphere *spheres, uint32_t n_spheres, const kl_quad *quads, uint32_t n_quads,
                                 const kl_tri *tris, uint32_t n_tris);
 KL_API kl_status kl_get_bvh_stats(kl_ctx *ctx, kl_bvh_stats *out);
+/* The uploaded scene, packed and with its tree, as ONE relocatable block in device memory (no reference counterpart). One
+ * process builds the tree (kl_upload_scene), exports the block, and hands it to the other GPUs' contexts -- e.g. one
+ * RCCL broadcast -- which import it instead of building the same tree again: kl_scene_blob_bytes gives the block's size,
+ * kl_scene_export writes it to dst_device (a device pointer on the context's device, exactly that many bytes),
+ * kl_scene_import reads such a block from src_device and makes it the context's scene, as kl_upload_scene would have
+ * (frame counter back to 0; kl_refit_scene works on it; textures are not part of the block). Record references are
+ * indices, so the block is valid on any device. The header's sizes are checked against `bytes` before anything is copied:
+ * KL_E_INVALID for a block that is not one of this library version's. */
+KL_API kl_status kl_scene_blob_bytes(kl_ctx *ctx, size_t *bytes);
+KL_API kl_status kl_scene_export(kl_ctx *ctx, void *dst_device, size_t bytes);
+KL_API kl_status kl_scene_import(kl_ctx *ctx, const void *src_device, size_t bytes);
 /* synthetic benchmark scene (no reference counterpart): sizes first, then fill caller-owned arrays */
 KL_API kl_status kl_synth_scene_counts(const kl_synth_params *sp, uint32_t *n_spheres, uint32_t *n_quads,
                                        uint32_t *n_tris, uint32_t *n_materials);

@@ -809,6 +809,117 @@ static kl_status kl_refit_scene_body(kl_ctx *c, const kl_sphere *s, uint32_t ns,
 kl_status kl_refit_scene(kl_ctx *c, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt) {
     return guarded(c, [&]() { return kl_refit_scene_body(c, s, ns, q, nq, t, nt); });
 }
+// ---- the packed scene as one relocatable block (kl_scene_export / kl_scene_import): header, record array, shading records,
+// flat-quad table, flat-quad indices. Record references are indices, so the block is valid on any device.
+namespace {
+struct SceneBlobHeader {
+    uint32_t magic, version;
+    uint64_t bytes;                     // of the whole block
+    uint64_t n_rec_f4, n_shrec_f4, n_flatq_f4, n_flat_index;
+    uint32_t n_nodes, n_prims;
+    int32_t root, tree_root;
+    uint32_t base[3], count[3], flat_start[3], flat_count[3];
+    kl_bvh_stats stats;
+};
+constexpr uint32_t SCENE_BLOB_MAGIC = 0x43534C4Bu, SCENE_BLOB_VERSION = 1u;   // "KLSC"
+constexpr size_t SCENE_BLOB_HEADER_BYTES = 512;
+static_assert(sizeof(SceneBlobHeader) <= SCENE_BLOB_HEADER_BYTES, "header block too small");
+size_t round256(size_t x) { return (x + 255u) & ~(size_t)255u; }
+struct SceneBlobLayout { size_t rec, shrec, flatq, index, total; };
+SceneBlobLayout blob_layout(uint64_t n_rec_f4, uint64_t n_shrec_f4, uint64_t n_flatq_f4, uint64_t n_index) {
+    SceneBlobLayout l;
+    l.rec = SCENE_BLOB_HEADER_BYTES;
+    l.shrec = l.rec + round256(n_rec_f4 * sizeof(float4));
+    l.flatq = l.shrec + round256(n_shrec_f4 * sizeof(float4));
+    l.index = l.flatq + round256(n_flatq_f4 * sizeof(float4));
+    l.total = l.index + round256(n_index * sizeof(uint32_t));
+    return l;
+}
+}  // namespace
+
+kl_status kl_scene_blob_bytes(kl_ctx *c, size_t *bytes) {
+    if (!c || !bytes) return KL_E_INVALID;
+    if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");
+    *bytes = blob_layout(c->d_rec.n, c->d_shrec.n, c->h_flatq.size(), c->flat_quad_index.size()).total;
+    return KL_OK;
+}
+static kl_status kl_scene_export_body(kl_ctx *c, void *dst, size_t bytes) {
+    if (!c || !dst) return KL_E_INVALID;
+    if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");
+    const SceneBlobLayout l = blob_layout(c->d_rec.n, c->d_shrec.n, c->h_flatq.size(), c->flat_quad_index.size());
+    if (bytes != l.total) return fail(c, KL_E_INVALID, "kl_scene_export: the block is kl_scene_blob_bytes() long");
+    KL_HIP(c, hipSetDevice(c->device));
+    std::vector<unsigned char> head(SCENE_BLOB_HEADER_BYTES, 0);
+    SceneBlobHeader h; std::memset(&h, 0, sizeof h);
+    h.magic = SCENE_BLOB_MAGIC; h.version = SCENE_BLOB_VERSION; h.bytes = l.total;
+    h.n_rec_f4 = c->d_rec.n; h.n_shrec_f4 = c->d_shrec.n; h.n_flatq_f4 = c->h_flatq.size(); h.n_flat_index = c->flat_quad_index.size();
+    h.n_nodes = c->sc.n_nodes; h.n_prims = c->n_prims; h.root = c->sc.root; h.tree_root = c->tree_root;
+    for (int k = 0; k < 3; k++) { h.base[k] = c->sc.base[k]; h.count[k] = c->sc.count[k]; h.flat_start[k] = c->sc.flat_start[k]; h.flat_count[k] = c->sc.flat_count[k]; }
+    h.stats = c->bvh_stats;
+    std::memcpy(head.data(), &h, sizeof h);
+    unsigned char *d = (unsigned char *)dst;
+    KL_HIP(c, hipMemcpyAsync(d, head.data(), head.size(), hipMemcpyHostToDevice, c->stream));
+    KL_HIP(c, hipMemcpyAsync(d + l.rec, c->d_rec.p, c->d_rec.n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    KL_HIP(c, hipMemcpyAsync(d + l.shrec, c->d_shrec.p, c->d_shrec.n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    if (!c->h_flatq.empty())
+        KL_HIP(c, hipMemcpyAsync(d + l.flatq, c->h_flatq.data(), c->h_flatq.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    if (!c->flat_quad_index.empty())
+        KL_HIP(c, hipMemcpyAsync(d + l.index, c->flat_quad_index.data(), c->flat_quad_index.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    KL_HIP(c, hipStreamSynchronize(c->stream));         // `head` goes out of scope
+    return KL_OK;
+}
+kl_status kl_scene_export(kl_ctx *c, void *dst_device, size_t bytes) {
+    return guarded(c, [&]() { return kl_scene_export_body(c, dst_device, bytes); });
+}
+static kl_status kl_scene_import_body(kl_ctx *c, const void *src, size_t bytes) {
+    if (!c || !src) return KL_E_INVALID;
+    if (bytes < SCENE_BLOB_HEADER_BYTES) return fail(c, KL_E_INVALID, "kl_scene_import: block shorter than its header");
+    KL_HIP(c, hipSetDevice(c->device));
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    SceneBlobHeader h;
+    KL_HIP(c, hipMemcpy(&h, src, sizeof h, hipMemcpyDeviceToHost));
+    if (h.magic != SCENE_BLOB_MAGIC || h.version != SCENE_BLOB_VERSION) return fail(c, KL_E_INVALID, "kl_scene_import: not a packed scene of this library version");
+    // every size is checked against the block before anything is allocated or copied
+    if (h.n_rec_f4 > (uint64_t)MAX_RECORDS * 4 || h.n_shrec_f4 > (uint64_t)MAX_RECORDS * 4 || h.n_flatq_f4 > 5u * 32u || h.n_flat_index > 32u ||
+        h.n_rec_f4 % 4 || h.n_shrec_f4 % 4 || h.n_rec_f4 == 0 || h.n_shrec_f4 == 0 || h.n_flatq_f4 != 5 * h.n_flat_index)
+        return fail(c, KL_E_INVALID, "kl_scene_import: sizes in the header are not those of a packed scene");
+    const SceneBlobLayout l = blob_layout(h.n_rec_f4, h.n_shrec_f4, h.n_flatq_f4, h.n_flat_index);
+    if (h.bytes != l.total || bytes != l.total) return fail(c, KL_E_INVALID, "kl_scene_import: block length does not match its header");
+    const uint64_t n_rec = h.n_rec_f4 / 4, prims = (uint64_t)h.count[0] + h.count[1] + h.count[2];
+    bool ok = h.n_nodes <= n_rec && prims == h.n_prims && (uint64_t)h.n_nodes + prims <= n_rec && h.n_shrec_f4 / 4 >= std::max<uint64_t>(prims, 1) &&
+              h.base[0] == h.n_nodes && h.base[1] == h.base[0] + h.count[0] && h.base[2] == h.base[1] + h.count[1] && h.flat_count[PRIM_QUAD] == h.n_flat_index;
+    for (int k = 0; k < 3 && ok; k++)
+        ok = h.flat_count[k] <= h.count[k] && h.flat_start[k] >= h.base[k] && (uint64_t)h.flat_start[k] + h.flat_count[k] <= (uint64_t)h.base[k] + h.count[k];
+    if (ok && h.root != NODE_DONE) {
+        if (h.root >= 0) ok = (uint32_t)h.root < h.n_nodes;
+        else { const uint32_t lv = (uint32_t)~h.root, start = lv & 0x3FFFFFFu, cnt = ((lv >> 26) & 7u) + 1u; ok = (uint64_t)start + cnt <= n_rec; }
+    }
+    if (!ok) return fail(c, KL_E_INVALID, "kl_scene_import: inconsistent counts in the header");
+    const unsigned char *sp = (const unsigned char *)src;
+    std::vector<float4> flatq(h.n_flatq_f4);
+    std::vector<uint32_t> index(h.n_flat_index);
+    if (!flatq.empty()) KL_HIP(c, hipMemcpy(flatq.data(), sp + l.flatq, flatq.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    if (!index.empty()) KL_HIP(c, hipMemcpy(index.data(), sp + l.index, index.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t qi : index) if (qi >= h.count[PRIM_QUAD]) return fail(c, KL_E_INVALID, "kl_scene_import: flat-quad index out of range");
+    KL_HIP(c, c->d_rec.alloc(h.n_rec_f4)); KL_HIP(c, c->d_shrec.alloc(h.n_shrec_f4));
+    KL_HIP(c, hipMemcpyAsync(c->d_rec.p, sp + l.rec, h.n_rec_f4 * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    KL_HIP(c, hipMemcpyAsync(c->d_shrec.p, sp + l.shrec, h.n_shrec_f4 * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    kl_status st;
+    if ((st = upload(c, c->d_flatq, flatq.data(), flatq.size())) != KL_OK) return st;
+    KL_HIP(c, hipStreamSynchronize(c->stream));
+    c->h_flatq = flatq; c->flat_quad_index = index;
+    c->sc.rec = c->d_rec.p; c->sc.shrec = c->d_shrec.p; c->sc.flatq = c->d_flatq.p;
+    c->sc.root = h.root; c->sc.n_nodes = h.n_nodes; c->tree_root = h.tree_root;
+    for (int k = 0; k < 3; k++) { c->sc.base[k] = h.base[k]; c->sc.count[k] = h.count[k]; c->sc.flat_start[k] = h.flat_start[k]; c->sc.flat_count[k] = h.flat_count[k]; }
+    c->n_prims = h.n_prims;
+    c->bvh_stats = h.stats;
+    c->have_scene = true;
+    return kl_reset(c);
+}
+kl_status kl_scene_import(kl_ctx *c, const void *src_device, size_t bytes) {
+    return guarded(c, [&]() { return kl_scene_import_body(c, src_device, bytes); });
+}
+
 kl_status kl_get_bvh_stats(kl_ctx *c, kl_bvh_stats *out) {
     if (!c || !out) return KL_E_INVALID;
     if (!c->have_scene) return fail(c, KL_E_STATE, "no scene uploaded");

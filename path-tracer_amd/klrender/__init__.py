@@ -105,6 +105,9 @@ SIGNATURES = {
     "kl_get_timing": (C.c_int32, [_P, C.POINTER(Timing)]),
     "kl_trace_rays": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _P]),
     "kl_get_stream": (C.c_int32, [_P, _P]),
+    "kl_scene_blob_bytes": (C.c_int32, [_P, C.POINTER(C.c_size_t)]),
+    "kl_scene_export": (C.c_int32, [_P, _P, C.c_size_t]),
+    "kl_scene_import": (C.c_int32, [_P, _P, C.c_size_t]),
     "kl_trace_rays_noalloc": (C.c_int32, [_P, _P, _P, C.c_uint32, _P, _P, _P]),
     "kl_set_shard": (C.c_int32, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "kl_get_local_rows": (C.c_int32, [_P, C.POINTER(C.c_uint32)]),
@@ -375,6 +378,19 @@ class Renderer:
         uv = np.empty((n, 2), dtype=np.float32)
         self._ck(lib().kl_trace_rays(self._h, _ptr(o), _ptr(d), n, _ptr(t), _ptr(prim), _ptr(uv)), "kl_trace_rays")
         return t, prim, uv
+
+    def scene_blob_bytes(self):
+        n = C.c_size_t()
+        self._ck(lib().kl_scene_blob_bytes(self._h, C.byref(n)), "kl_scene_blob_bytes")
+        return n.value
+
+    def scene_export(self, device_ptr, nbytes):
+        """the packed scene (records, tree, shading records, flat-quad table) into device memory at device_ptr"""
+        self._ck(lib().kl_scene_export(self._h, C.c_void_p(device_ptr), nbytes), "kl_scene_export")
+
+    def scene_import(self, device_ptr, nbytes):
+        """a block written by scene_export (on any device) becomes this context's scene"""
+        self._ck(lib().kl_scene_import(self._h, C.c_void_p(device_ptr), nbytes), "kl_scene_import")
 
     def stream(self):
         """the context's HIP stream as an integer handle (kl_get_stream)"""

@@ -62,9 +62,31 @@ def _device_of(renderer):
     return torch.device("cuda", renderer.device)
 
 
-def render_tiles(renderer, n_frames, band_rows, first_frame=0, group=None, gatherer=None):
+def _split_timing(renderer, timing, t0):
+    """`timing` (a dict, measurement runs only): wait for the render, note its wall time, return the exchange's start"""
+    import time
+    if timing is None:
+        return None
+    renderer.synchronize()
+    t1 = time.perf_counter()
+    timing["render_s"] = timing.get("render_s", 0.0) + (t1 - t0)
+    return t1
+
+
+def _end_timing(timing, device, t1):
+    import time
+    if timing is None:
+        return
+    torch.cuda.synchronize(device)
+    timing["exchange_s"] = timing.get("exchange_s", 0.0) + (time.perf_counter() - t1)
+
+
+def render_tiles(renderer, n_frames, band_rows, first_frame=0, group=None, gatherer=None, timing=None):
     """Image-tile partition on the HIP path: shards `renderer` by row bands, renders, gathers. `gatherer`: a TileGather
-    to reuse between calls (its buffers are then not reallocated)."""
+    to reuse between calls (its buffers are then not reallocated). `timing`: a dict that receives the wall time of the
+    render and of the exchange (all-gather + un-tile) separately, at the price of a wait between the two."""
+    import time
+    t0 = time.perf_counter()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if renderer.shard != (rank, world, band_rows):
         renderer.set_shard(rank, world, band_rows)
@@ -75,10 +97,13 @@ def render_tiles(renderer, n_frames, band_rows, first_frame=0, group=None, gathe
     assert tg.rows == renderer.local_rows
     # torch's stream may still read the block (previous gather): wait, then let the renderer's stream copy into it
     torch.cuda.current_stream(tg.gathered.device).synchronize()
+    t1 = _split_timing(renderer, timing, t0)
     if tg.rows:
         view = tg.local_view()
         renderer.copy_accum_to_device(view.data_ptr(), view.numel() * 4)
-    return tg.gather()
+    out = tg.gather()
+    _end_timing(timing, tg.gathered.device, t1)
+    return out
 
 
 def live_frames(first_frame, n_frames, max_frames):
@@ -89,10 +114,13 @@ def live_frames(first_frame, n_frames, max_frames):
     return max(0, min(first_frame + n_frames, max_frames) - first_frame)
 
 
-def render_sample_ranges(renderer, n_frames, first_frame=0, group=None, out=None):
+def render_sample_ranges(renderer, n_frames, first_frame=0, group=None, out=None, timing=None):
     """Sample-range partition on the HIP path: every rank sums its frame range over the full image; returns the
-    mean over all ranks' frames. `out`: an (H, W, 4) float32 tensor on the renderer's device to reuse between calls."""
+    mean over all ranks' frames. `out`: an (H, W, 4) float32 tensor on the renderer's device to reuse between calls.
+    `timing`: as in render_tiles (render and all-reduce + divide timed separately)."""
+    import time
     from . import ACCUM_SUM
+    t0 = time.perf_counter()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi = partition.frame_range(first_frame, n_frames, rank, world)
     renderer.set_accum_mode(ACCUM_SUM)
@@ -104,9 +132,45 @@ def render_sample_ranges(renderer, n_frames, first_frame=0, group=None, out=None
     # `local` may still be read by the previous call's all_reduce / divide on torch's stream, and the copy below runs
     # on the renderer's stream: wait for torch's side first
     torch.cuda.current_stream(local.device).synchronize()
+    t1 = _split_timing(renderer, timing, t0)
     if hi > lo:
         renderer.copy_accum_to_device(local.data_ptr(), local.numel() * 4)
     else:
         local.zero_()
     live = live_frames(first_frame, n_frames, renderer.get_params().max_frames)
-    return reduce_samples(local, max(live, 1), group)
+    res = reduce_samples(local, max(live, 1), group)
+    _end_timing(timing, local.device, t1)
+    return res
+
+
+def upload_scene_once(renderer, scene, src=0, group=None):
+    """The tree is built ONCE per job: rank `src` uploads `scene` (spheres, quads, tris, materials; the other ranks may pass
+    None), exports the packed scene -- records, tree, shading records, flat-quad table -- as one block of device memory,
+    and one broadcast hands it to every other rank, which imports it instead of building the same tree again (N ranks of a
+    node would otherwise run N multi-threaded host builds side by side). With the "nccl" backend the block travels from
+    GPU to GPU over RCCL; with "gloo" (CPU tests, rehearsals) through host memory. Returns the block (a uint8 tensor on the
+    renderer's device): another context on this device can import it again without a new build or broadcast."""
+    rank = dist.get_rank(group)
+    dev = _device_of(renderer)
+    nbytes = torch.zeros(1, dtype=torch.int64)
+    if rank == src:
+        renderer.upload_scene(*scene)
+        nbytes[0] = renderer.scene_blob_bytes()
+    via_host = dist.get_backend(group) != "nccl"
+    size = nbytes if via_host else nbytes.to(dev)
+    dist.broadcast(size, src=src, group=group)
+    n = int(size.item())
+    block = torch.empty(n, dtype=torch.uint8, device=dev)
+    if rank == src:
+        renderer.scene_export(block.data_ptr(), n)
+    if via_host:
+        host = block.cpu() if rank == src else torch.empty(n, dtype=torch.uint8)
+        dist.broadcast(host, src=src, group=group)
+        if rank != src:
+            block.copy_(host)
+    else:
+        dist.broadcast(block, src=src, group=group)
+    if rank != src:
+        torch.cuda.synchronize(dev)
+        renderer.scene_import(block.data_ptr(), n)
+    return block

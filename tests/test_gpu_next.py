@@ -326,3 +326,62 @@ def test_refit_of_a_million_triangles():
     assert_bitexact(ta, tb, "1M triangles refitted vs rebuilt: t"); assert_bitexact(ua, ub, "uv")
     print("1M triangles: host SAH build %.4f s, refit %.4f s" % (build, refit))
     assert refit < build
+
+
+def test_packed_scene_block_import_equals_a_fresh_upload(textures):
+    """kl_scene_export / kl_scene_import: the packed scene (records, tree, shading records, flat-quad table) leaves one
+    context as a block of device memory and becomes another context's scene: same hits and same pixels, bit for bit, as the
+    context that built the tree; the imported scene can be refitted; damaged blocks are refused before anything is copied."""
+    import torch
+    from test_gpu_scene import random_rays
+    s, q, t, m = kl.synth_scene(blobs=24, tris_per_blob=160, analytic_spheres=40, seed=3)
+    o, d = random_rays(20000, 41)
+    w, h = 96, 54
+    dev = torch.device("cuda", 0)
+    with kl.Renderer(w, h) as a, kl.Renderer(w, h) as b:
+        with pytest.raises(kl.KlError, match="invalid state"):
+            a.scene_blob_bytes()
+        a.update_params(max_bounces=8, max_frames=0, accel=kl.ACCEL_BVH)
+        b.update_params(max_bounces=8, max_frames=0, accel=kl.ACCEL_BVH)
+        a.upload_scene(s, q, t, m)
+        n = a.scene_blob_bytes()
+        assert n > 64 * (len(s) + len(q) + len(t)) * 2
+        block = torch.zeros(n, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        with pytest.raises(kl.KlError):
+            a.scene_export(block.data_ptr(), n - 256)
+        a.scene_export(block.data_ptr(), n)
+        # refused: truncated, a foreign header, a header whose sizes do not add up to the block
+        with pytest.raises(kl.KlError):
+            b.scene_import(block.data_ptr(), 128)
+        with pytest.raises(kl.KlError):
+            b.scene_import(block.data_ptr(), n - 256)
+        bad = block.clone(); bad[0] ^= 0xFF
+        torch.cuda.synchronize(dev)
+        with pytest.raises(kl.KlError, match="not a packed scene"):
+            b.scene_import(bad.data_ptr(), n)
+        bad = block.clone(); bad[16:24] = torch.tensor([0xFF] * 7 + [0x00], dtype=torch.uint8, device=dev)     # n_rec_f4: huge
+        torch.cuda.synchronize(dev)
+        with pytest.raises(kl.KlError):
+            b.scene_import(bad.data_ptr(), n)
+        with pytest.raises(kl.KlError, match="invalid state"):
+            b.render_frames(1)                                # none of the refused blocks became a scene
+        b.scene_import(block.data_ptr(), n)
+        del block, bad
+        sa, sb = a.bvh_stats(), b.bvh_stats()
+        assert (sa.nodes, sa.leaves, sa.max_depth, sa.flat_quads, sa.tris, sa.spheres) == (sb.nodes, sb.leaves, sb.max_depth, sb.flat_quads, sb.tris, sb.spheres)
+        ta, pa, ua = a.trace_rays(o, d)
+        tb, pb, ub = b.trace_rays(o, d)
+        assert (pa != kl.MISS).mean() > 0.9 and np.array_equal(pa, pb)
+        assert_bitexact(ta, tb, "imported scene: t"); assert_bitexact(ua, ub, "imported scene: uv")
+        for r in (a, b):
+            r.upload_texture(kl.TEX_HDRI, textures["hdri"]); r.upload_texture(kl.TEX_ALBEDO, textures["albedo"])
+            r.render_frames(3)
+        assert_bitexact(a.read_accum(), b.read_accum(), "imported scene, path traced")
+        # the imported scene carries what a refit needs (flat-quad indices, tree root)
+        s2, q2, t2 = _moved(s, q, t, 5)
+        a.refit_scene(s2, q2, t2); b.refit_scene(s2, q2, t2)
+        ta, pa, ua = a.trace_rays(o, d)
+        tb, pb, ub = b.trace_rays(o, d)
+        assert np.array_equal(pa, pb)
+        assert_bitexact(ta, tb, "imported scene, refitted: t"); assert_bitexact(ua, ub, "imported scene, refitted: uv")

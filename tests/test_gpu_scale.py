@@ -179,9 +179,12 @@ def test_bench_with_two_ranks_on_one_gpu(partition, scaling):
     import sys
     port = free_port()
     env = dict(os.environ, KL_BENCH_BACKEND="gloo")
+    # the other BASELINE multi-GPU lines ride along as sub-records (toy sizes here) in one of the three runs
+    extras = "small" if (partition, scaling) == ("samples", "weak") else "none"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "180", "--spp", "8",
-           "--blobs", "20", "--tris-per-blob", "200", "--partition", partition, "--scaling", scaling, "--skip-kernels", "--cpu-seconds", "0"]
+           "--blobs", "20", "--tris-per-blob", "200", "--partition", partition, "--scaling", scaling, "--skip-kernels", "--cpu-seconds", "0",
+           "--extras", extras]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
@@ -190,4 +193,17 @@ def test_bench_with_two_ranks_on_one_gpu(partition, scaling):
     assert j["scaling"] == scaling and j["value"] > 0 and j["higher_is_better"] is True
     frames_total = 16 if (partition, scaling) == ("samples", "weak") else 8
     assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 320 * 180 * frames_total) <= 1e-6 * 320 * 180 * frames_total     # value = whole-job samples / time
+    # the tree is built once: rank 0 uploads, the other rank imports the broadcast block
+    assert "built once on rank 0" in j["config"]["scene_upload"] and j["config"]["triangles"] == 20 * 180
+    if extras == "small":
+        m = j["multi_gpu"]
+        for key, mode, image, frames in (("strong", "samples", "320x180", 8), ("config4_tiles", "tiles", "640x360", 16), ("config5_samples", "samples", "640x360", 32)):
+            c = m[key]
+            assert c["partition"] == mode and c["image"] == image and c["frames_in_all"] == frames and c["rccl_ranks"] == 2
+            assert c["samples_per_s"] > 0 and c["ms_per_step"] > 0 and c["exchange_ms"] > 0 and c["mrays_per_s"] > 0
+            w, h = (int(v) for v in image.split("x"))
+            assert abs(c["samples_per_s"] * c["ms_per_step"] * 1e-3 - w * h * frames) <= 1e-6 * w * h * frames
+        assert m["config5_samples"]["primitives"] == 60 * 180 + 50 + 7 and m["config5_samples"]["packed_scene_mb"] > 1
+    else:
+        assert j["multi_gpu"] is None
     assert "gloo" in j["config"]["partition"]

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 from klrender import partition
 
 
@@ -91,7 +91,7 @@ def _worker(rank, world, port, height, width, band_rows, n_frames, out_dir):
 @pytest.mark.parametrize("height,band_rows", [(27, 4), (20, 16)])
 def test_two_rank_gather_and_reduce(tmp_path, height, band_rows):
     world, width, n_frames = 2, 48, 6
-    port = 29500 + (os.getpid() % 2000) + height
+    port = free_port()
     mp.spawn(_worker, args=(world, port, height, width, band_rows, n_frames, str(tmp_path)), nprocs=world, join=True)
     full = np.load(tmp_path / "full.npy")
     for r in range(world):

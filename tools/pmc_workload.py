@@ -34,6 +34,9 @@ r.reset_counters()
 r.render_frames(spp, first_frame=0)
 r.synchronize()
 c = r.counters()
+from klrender import codeid  # noqa: E402
+types = codeid.traversal_types(r.bvh_stats())
 print(json.dumps({"spp": spp, "paths": c.paths, "rays": c.rays, "batch_lanes": lanes, "config": config,
-                  "width": pre["width"], "height": pre["height"], "primitives": len(scene[0]) + len(scene[1]) + len(scene[2])}))
+                  "width": pre["width"], "height": pre["height"], "primitives": len(scene[0]) + len(scene[1]) + len(scene[2]),
+                  "traversal_types": types, "code": codeid.render_code_identity(kl.LIB_PATH, types)}))
 r.close()

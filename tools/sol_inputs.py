@@ -14,7 +14,10 @@ VALU issue time of a kernel = sum over its executed wave-instructions of the clo
 The hardware counts executed instructions by class: SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 (2 clk each), _TRANS_F32 (8), _CVT (4); the
 remainder (integer, logic, moves, compares, selects, min/max) has no class counter that separates 2- from 4-clock opcodes, so
 it is priced at the average cost of those opcodes in the kernel's own code (static mix, `rest_cost_static`).
-usage: tools/sol_inputs.py <tag> [isa.s]"""
+Every kernel's figures are stamped with the hash of that kernel's machine code in the library the counter passes ran on
+(`code`, printed by tools/pmc_workload.py into the header line of each pass): bench.py compares it with the library it
+loads and reports no issue / traffic fraction for a kernel whose code has changed since.
+usage: tools/sol_inputs.py <tag> [isa.s]     (<tag>_pmc_passes.txt names the configuration and the traversal instance)"""
 import json
 import os
 import re
@@ -27,9 +30,14 @@ EIGHT = {"v_rcp_f32", "v_rcp_iflag_f32", "v_rsq_f32", "v_sqrt_f32", "v_exp_f32",
 CLASSED = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32"} | EIGHT   # + v_cvt_*: have class counters
 N_SIMD, PEAK_CLOCK_HZ = 1024, 2.4e9
 L2_BYTES_PER_S, FABRIC_BYTES_PER_S = 34.5e12, 6.3e12      # L2 aggregate; HBM achievable (hardware guide)
-KERNELS = {"intersect": r"k_intersect_bvh<(0|false), 4u>", "shade": r"k_shade<1>", "generate": r"k_generate", "accumulate": r"k_accumulate"}
-MANGLED = {"intersect": "_ZN2kl15k_intersect_bvhILi0ELj4EE", "shade": "_ZN2kl7k_shadeILi1EE", "generate": "_ZN2kl10k_generate",
-           "accumulate": "_ZN2kl12k_accumulate"}
+
+
+def kernel_names(types):
+    """(rocprof name patterns, mangled prefixes) of a step's kernels when the tree holds the primitive types `types`"""
+    kernels = {"intersect": r"k_intersect_bvh<(0|false), %du>" % types, "shade": r"k_shade<1>", "generate": r"k_generate", "accumulate": r"k_accumulate"}
+    mangled = {"intersect": "_ZN2kl15k_intersect_bvhILi0ELj%dEE" % types, "shade": "_ZN2kl7k_shadeILi1EE", "generate": "_ZN2kl10k_generate",
+               "accumulate": "_ZN2kl12k_accumulate"}
+    return kernels, mangled
 
 
 def base(op):
@@ -40,9 +48,9 @@ def cost(op):
     return 2 if op in TWO else 8 if op in EIGHT else 4
 
 
-def isa_mix(path):
+def isa_mix(path, mangled):
     out = {}
-    for key, prefix in MANGLED.items():
+    for key, prefix in mangled.items():
         on, ops = False, {}
         for l in open(path):
             if not on:
@@ -104,15 +112,23 @@ def single_lane(path):
 
 def main(tag, isa):
     prof = os.path.join(ROOT, "profiles")
-    mix = isa_mix(isa)
-    json.dump(mix, open(os.path.join(prof, tag + "_isa_mix.json"), "w"), indent=1)
     P = parse_passes(os.path.join(prof, tag + "_pmc_passes.txt"))
+    step = P["mix"]["step"]
+    types, config = step.get("traversal_types", 4), step.get("config", 3)
+    KERNELS, MANGLED = kernel_names(types)
+    mix = isa_mix(isa, MANGLED)
+    json.dump(mix, open(os.path.join(prof, tag + "_isa_mix.json"), "w"), indent=1)
     SL = single_lane(os.path.join(prof, tag + "_kernel_stats_single_lane.md"))
-    rays = P["mix"]["step"]["rays"]
-    paths = P["mix"]["step"]["paths"]
-    out = {"tag": tag, "workload": "one 64-spp step of BASELINE configs[2] (tools/pmc_workload.py): %d paths, %d rays" % (paths, rays),
+    rays = step["rays"]
+    paths = step["paths"]
+    codes = [P[p]["step"].get("code") for p in P]
+    if any(c != codes[0] for c in codes):
+        sys.exit("the counter passes of %s ran on different builds of the kernels: %r" % (tag, codes))
+    out = {"tag": tag, "config": config, "traversal_types": types,
+           "workload": "one %d-spp step of BASELINE configs[%d] (tools/pmc_workload.py): %d paths, %d rays" % (step.get("spp", 64), config - 1, paths, rays),
            "rays_per_step": rays, "paths_per_step": paths, "n_simd": N_SIMD, "peak_clock_hz": PEAK_CLOCK_HZ,
-           "l2_bytes_per_s": L2_BYTES_PER_S, "fabric_bytes_per_s": FABRIC_BYTES_PER_S, "kernels": {}}
+           "l2_bytes_per_s": L2_BYTES_PER_S, "fabric_bytes_per_s": FABRIC_BYTES_PER_S,
+           "code": codes[0] or {}, "kernels": {}}
     for key, pat in KERNELS.items():
         m, t, l2, wr, fe = (pick(P[p]["kernels"], pat) for p in ("mix", "time", "l2", "write", "fetch"))
         if not m:
@@ -124,7 +140,8 @@ def main(tag, isa):
         c_rest = mix[key]["rest_cost_static"]
         issue = 2 * two + 8 * trans + 4 * cvt + c_rest * rest
         unit = paths if key in ("generate", "accumulate") else rays
-        k = {"unit": "path" if unit == paths else "ray", "launches_per_step": m["calls"],
+        k = {"unit": "path" if unit == paths else "ray", "launches_per_step": m["calls"], "kernel": pat.replace("(0|false)", "0"),
+             "code": (codes[0] or {}).get(key),
              "valu_insts": valu, "valu_2clk_float": two, "valu_trans": trans, "valu_cvt": cvt, "valu_rest": rest, "rest_cost_static": c_rest,
              "issue_clocks": issue, "issue_clocks_per_unit": issue / unit, "avg_clocks_per_valu_inst": issue / valu,
              "issue_clocks_if_rest_all_2clk": 2 * two + 8 * trans + 4 * cvt + 2 * rest,
