@@ -148,7 +148,9 @@ class KlError(RuntimeError):
 
 
 def lib():
-    """Loads libklrender.so; raises if it is absent (there is no other implementation)."""
+    """Loads libklrender.so; raises if it is absent (there is no other implementation). A process that also uses PyTorch on
+    the GPU imports torch BEFORE the first call here: torch ships its own copy of the HIP runtime and cannot initialise once
+    the system's copy, which this library names, is in the process (the other order works for both)."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):

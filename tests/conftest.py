@@ -4,6 +4,15 @@ import sys
 import numpy as np
 import pytest
 
+# Load order: PyTorch ships its own copy of the HIP runtime. If libklrender.so (which names the system's /opt/rocm copy) is
+# loaded first, PyTorch later binds to that already-loaded copy and cannot initialise ("No HIP GPUs are available"); loaded
+# the other way round both work. Tests that hand device memory to the library through torch tensors therefore need torch
+# in the process before the library, whatever subset of test files is collected.
+try:
+    import torch  # noqa: F401
+except Exception:          # the C-ABI tests themselves do not need it
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "path-tracer_amd"), ROOT):
