@@ -194,7 +194,7 @@ def test_bench_with_two_ranks_on_one_gpu(partition, scaling):
     frames_total = 16 if (partition, scaling) == ("samples", "weak") else 8
     assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 320 * 180 * frames_total) <= 1e-6 * 320 * 180 * frames_total     # value = whole-job samples / time
     # the tree is built once: rank 0 uploads, the other rank imports the broadcast block
-    assert "built once on rank 0" in j["config"]["scene_upload"] and j["config"]["triangles"] == 20 * 180
+    assert "built once on rank 0" in j["config"]["scene_upload"] and j["config"]["triangles"] == 20 * 200
     if extras == "small":
         m = j["multi_gpu"]
         for key, mode, image, frames in (("strong", "samples", "320x180", 8), ("config4_tiles", "tiles", "640x360", 16), ("config5_samples", "samples", "640x360", 32)):
@@ -203,7 +203,7 @@ def test_bench_with_two_ranks_on_one_gpu(partition, scaling):
             assert c["samples_per_s"] > 0 and c["ms_per_step"] > 0 and c["exchange_ms"] > 0 and c["mrays_per_s"] > 0
             w, h = (int(v) for v in image.split("x"))
             assert abs(c["samples_per_s"] * c["ms_per_step"] * 1e-3 - w * h * frames) <= 1e-6 * w * h * frames
-        assert m["config5_samples"]["primitives"] == 60 * 180 + 50 + 7 and m["config5_samples"]["packed_scene_mb"] > 1
+        assert m["config5_samples"]["primitives"] == 60 * 200 + 50 + 7 and m["config5_samples"]["packed_scene_mb"] > 1
     else:
         assert j["multi_gpu"] is None
     assert "gloo" in j["config"]["partition"]
