@@ -130,6 +130,13 @@ def test_ten_million_primitive_mixed_scene(textures):
         raw = r.read_raw()
         cn = r.counters()
     assert np.isfinite(raw).all() and raw[..., :3].max() > 0 and cn.paths == 3840 * 2160
+    # frame 0 at the configuration's full size, three full-width row bands, bit for bit against the CPU oracle (its own tree)
+    sc = ko.Scene(s, q, t, m)
+    sc.set_texture(ko.TEX_HDRI, textures["hdri"]); sc.set_texture(ko.TEX_ALBEDO, textures["albedo"])
+    p = ko.default_params(width=3840, height=2160, mode=ko.MODE_PT, max_frames=0, max_bounces=8, use_bvh=1)
+    for y0 in (0, 1079, 2157):
+        want = sc.render_raw(ko.default_camera(), p, 0, rows=(y0, y0 + 3))
+        assert_bitexact(raw[y0:y0 + 3], want[y0:y0 + 3], "10 M primitives, rows %d..%d" % (y0, y0 + 2))
 
 
 def test_dist_partitions_through_rccl_with_one_rank(textures):
