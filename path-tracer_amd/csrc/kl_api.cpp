@@ -496,7 +496,10 @@ static kl_status kl_create_body(kl_ctx **out, int32_t device, uint32_t width, ui
 #define KL_ISECT_BLOCKS_PER_CU 6     // 4 waves x (2.5 KiB stack + 4.1 KiB fetch staging) -> six workgroups share a CU's 160 KiB LDS
 #endif
     c->lc.isect_blocks_per_cu = KL_ISECT_BLOCKS_PER_CU;
-    c->lc.shade_blocks_per_cu = 8;
+    // Shade's grid: its blocks share a segment's rays equally, and a CU holds six of them (74 VGPRs). A grid of 8 per CU runs as
+    // one full round and a second one a third full (21.1 ms per 64-spp step); many small blocks even that out (17.9 ms at 48
+    // per CU and beyond). With two batch lanes the other lane's traversal used to fill that gap, so the step time is the same.
+    c->lc.shade_blocks_per_cu = 48;
     if (const char *e = std::getenv("KL_SHADE_BLOCKS_PER_CU")) c->lc.shade_blocks_per_cu = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("KL_FLAT_SEPARATE")) c->flat_separate = e[0] == '1';
     c->width = width; c->height = height;
