@@ -385,6 +385,26 @@ def test_resolve_matches_present_pass(textures):
             assert np.array_equal(r.resolve(tm), ko.resolve(acc, otm))
 
 
+def test_present_pass_conversion_on_ties_and_specials(textures):
+    """k_resolve on an image of exact ties, out-of-range values, NaN and infinities (written into the accumulation through
+    kl_copy_accum_from_device): the oracle's bytes, i.e. clamp + rint(x * 255) with ties to even, as the attachments round"""
+    import torch
+    from test_oracle_golden import present_pass_probe
+    img, _ = present_pass_probe()
+    with make_renderer(64, 36, textures) as r:
+        r.render_frames(1)
+        t = torch.from_numpy(img).to(torch.device("cuda", r.device))
+        torch.cuda.synchronize()
+        r.copy_accum_from_device(t.data_ptr(), t.numel() * 4)
+        assert_bitexact(r.read_accum(), img, "accumulation written from a device buffer")
+        assert np.array_equal(r.resolve(kl.TONEMAP_CLAMP), ko.resolve(img, ko.TONEMAP_CLAMP))
+        # the image kept through RGBA8 attachments resolves to the reference run's bytes (ZDepth: all of them)
+        g = golden("shipped_rgba8_64x36_8frames.npz")
+        r.set_mode(kl.MODE_Z); r.set_accum_mode(kl.ACCUM_MEAN_UNORM8); r.update_params(max_frames=0)
+        r.render_frames(8, first_frame=0)
+        assert np.array_equal(r.resolve(kl.TONEMAP_CLAMP)[..., :3], g["z_mean8"])
+
+
 def test_error_behaviour():
     with kl.Renderer(8, 8) as r:
         with pytest.raises(kl.KlError, match="invalid state"):

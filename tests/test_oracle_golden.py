@@ -336,6 +336,48 @@ def test_accumulation_as_shipped_through_rgba8(oracle_builtin):
         check_shipped_rgba8(key, acc, g[key])
 
 
+def tie_values():
+    """float32 values x with fl(x * 255) exactly half way between two 8-bit levels, one per level pair where such a float exists"""
+    out = []
+    for k in range(255):
+        x = np.float32((k + 0.5) / 255.0)
+        for cand in (x, np.nextafter(x, np.float32(0)), np.nextafter(x, np.float32(1))):
+            if np.float32(cand) * np.float32(255.0) == np.float32(k + 0.5):
+                out.append(np.float32(cand)); break
+    return np.array(out, dtype=np.float32)
+
+
+def present_pass_probe(h=36, w=64):
+    """an accumulation image that exercises the 8-bit conversion: exact ties, a fine ramp, values outside [0, 1], NaN, infinities"""
+    ties = tie_values()
+    assert len(ties) > 100
+    vals = np.concatenate([ties, np.linspace(-0.25, 1.25, 4000, dtype=np.float32),
+                           np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1.0, 0.5], dtype=np.float32)])
+    img = np.resize(vals, h * w * 4).astype(np.float32).reshape(h, w, 4)
+    return img, ties
+
+
+def test_present_pass_rounds_like_the_attachments(oracle_builtin):
+    """PostProcess.glsl:38 hands the accumulation texel to an 8-bit backbuffer: one conversion rule for it and for the RGBA8
+    attachments (clamp, rint(x * 255): ties to even, NaN -> 0), the rule the reference run with the application's own
+    attachment format pins. So the present pass of an image kept through those attachments gives the reference run's bytes."""
+    img, ties = present_pass_probe()
+    got = ko.resolve(img, ko.TONEMAP_CLAMP)
+    x = img.reshape(-1)
+    with np.errstate(invalid="ignore"):
+        want = np.rint(np.where(np.isnan(x), 0.0, np.clip(x, 0.0, 1.0)).astype(np.float32) * np.float32(255.0)).astype(np.uint8)
+    assert np.array_equal(got.reshape(-1), want)
+    t8 = ko.resolve(np.resize(ties, 64 * 36 * 4).reshape(36, 64, 4), ko.TONEMAP_CLAMP).reshape(-1)[:len(ties)]
+    assert (t8 % 2 == 0).all()                                  # every exact tie went to the even level
+    g = golden("shipped_rgba8_64x36_8frames.npz")
+    for mode, key in ((ko.MODE_PT, "pt_mean8"), (ko.MODE_Z, "z_mean8")):
+        p = ko.default_params(width=64, height=36, mode=mode, max_frames=0)
+        acc = ko.render_mean(oracle_builtin, ko.default_camera(), p, 8, unorm8=True)
+        shown = ko.resolve(acc, ko.TONEMAP_CLAMP)[..., :3].astype(np.int32)
+        same = np.mean(shown == g[key].astype(np.int32))
+        assert same == 1.0 if key.startswith("z") else same >= 0.997, (key, same)
+
+
 def test_rng_known_answers():
     """rand4() for seed (x, y, frame, x+y); values observed from the shader on llvmpipe."""
     kat = {
