@@ -497,76 +497,10 @@ def main():
             r.read_accum()
         readback_ms = 1e3 * (time.perf_counter() - t0) / 3
 
-    # ---- N > 1: the other BASELINE multi-GPU lines, untimed extras (every rank takes part in their collectives)
-    multi = None
-    if world > 1 and args.extras != "none" and (default_run or args.extras == "small"):
-        small = args.extras == "small"
-
-        def run_case(rr, mode, frames_all, h, w, steps):
-            runner = partition_runner(rr, mode, frames_all, h, w)
-            runner()                                      # warm-up (buffers, first touch)
-            rr.synchronize()
-            rr.reset_counters()
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                runner()
-                rr.synchronize()
-            fence()
-            dt = max_over_ranks(time.perf_counter() - t0)
-            rays = sum_over_ranks(rr.counters().rays)
-            # one more step with a wait between render and exchange, to time the exchange by itself
-            tm = {}
-            runner(timing=tm)
-            rr.synchronize()
-            return {"samples_per_s": float(h) * w * frames_all * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
-                    "mrays_per_s": rays / dt / 1e6, "frames_in_all": frames_all, "frames_per_rank": frames_all if mode == "tiles" else frames_all / world,
-                    "exchange_ms": 1e3 * max_over_ranks(tm.get("exchange_s", 0.0)), "render_ms_rank_max": 1e3 * max_over_ranks(tm.get("render_s", 0.0)),
-                    "rccl_ranks": dist.get_world_size(), "backend": collective, "partition": mode, "image": "%dx%d" % (w, h),
-                    "exchange": ("all-gather of %.1f MB per rank + un-tile" % (h * w * 16 / world / 1e6)) if mode == "tiles"
-                                else ("all-reduce(sum) of %.1f MB + divide" % (h * w * 16 / 1e6))}
-
-        multi = {"note": "untimed extras (not in `value`): the other BASELINE multi-GPU lines, each timed like the main region (barrier + "
-                         "synchronize on both sides, max over ranks); exchange_ms = the collective and its un-tile / divide alone, from one "
-                         "further step with a wait between render and exchange"}
-        # (1) strong scaling of the headline workload: spp frames in all, split over the ranks
-        multi["strong"] = run_case(r, "samples", spp, height, width, args.steps)
-        multi["strong"]["workload"] = "%s, %dx%d, %d spp in all, sample ranges" % (pre["name"], width, height, spp)
-        r.close()
-        r = None
-        # (2) BASELINE configs[3]: the same scene at 4K, 256 spp, image tiles; the packed scene is imported again, not rebuilt
-        w4, h4, spp4 = (3840, 2160, 256) if not small else (2 * width, 2 * height, 2 * spp)
-        r4 = kl.Renderer(w4, h4, device=device)
-        r4.scene_import(scene_block.data_ptr(), scene_block.numel())
-        r4.upload_texture(kl.TEX_HDRI, bg)
-        r4.upload_texture(kl.TEX_ALBEDO, tx)
-        r4.update_params(max_bounces=args.bounces, max_frames=0, trace_primary_per_frame=1)
-        multi["config4_tiles"] = run_case(r4, "tiles", spp4, h4, w4, 1 if not small else 2)
-        multi["config4_tiles"]["workload"] = "%s, %dx%d, %d spp, row bands of %d rows round-robin" % (PRESETS[4]["name"], w4, h4, spp4, args.band_rows)
-        r4.close()
-        scene_block = None
-        # (3) BASELINE configs[4]: 10 M primitives at 4K, 1024 spp in all, sample ranges; one host SAH build on rank 0, broadcast
-        w5, h5, spp5 = (3840, 2160, 1024) if not small else (2 * width, 2 * height, 4 * spp)
-        blobs5, spheres5 = (PRESETS[5]["blobs"], PRESETS[5]["spheres"]) if not small else (3 * blobs, 50)
-        r5 = kl.Renderer(w5, h5, device=device)
-        _, block5, scene5_s = make_scene(r5, blobs5, spheres5, args.tris_per_blob, args.builder)
-        r5.upload_texture(kl.TEX_HDRI, bg)
-        r5.upload_texture(kl.TEX_ALBEDO, tx)
-        r5.update_params(max_bounces=args.bounces, max_frames=0, trace_primary_per_frame=1)
-        b5 = r5.bvh_stats()
-        multi["config5_samples"] = run_case(r5, "samples", spp5, h5, w5, 1 if not small else 2)
-        multi["config5_samples"].update({"workload": "%s, %dx%d, %d spp in all" % (PRESETS[5]["name"], w5, h5, spp5),
-                                         "primitives": int(b5.tris + b5.spheres + b5.quads), "bvh_nodes": int(b5.nodes),
-                                         "scene_seconds_rank0_build_plus_broadcast": round(scene5_s, 2), "packed_scene_mb": round(block5.numel() / 1e6, 1)})
-        r5.close()
-        block5 = None
-
-    cpu = builtin = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        cpu = cpu_baseline(scene, (bg, tx), width, height, args.bounces, args.cpu_seconds)
-        if args.extras != "none":
-            builtin = builtin_figures(kl, device, (bg, tx))
-
+    # ---- the line, as far as the timed region and its single-GPU extras go. It is built BEFORE the remaining extras and printed
+    # exactly once: by the normal path with the extras' sub-records filled in, or -- if an extra raises or does not come back
+    # within its time budget (a collective that one rank left) -- by the guard below, with the reason in place of the sub-record.
+    out = None
     if rank == 0:
         if world == 1:
             part = "single GPU, running mean"
@@ -591,9 +525,115 @@ def main():
                        "bvh_builder": "GPU LBVH" if bvh.builder == kl.BUILD_GPU_LBVH else "host binned SAH",
                        "scene_upload": ("one build, this GPU" if world == 1 else "tree built once on rank 0, packed scene broadcast to %d ranks over %s" % (world - 1, collective)),
                        "scene_seconds": round(scene_s, 3), "textures": tex_note, "partition": part},
-            "roofline": roofline, "cpu_baseline": cpu, "builtin": builtin, "multi_gpu": multi,
+            "roofline": roofline, "cpu_baseline": None, "builtin": None, "multi_gpu": None,
         }
-        print(json.dumps(out))
+    import threading
+    emitted = threading.Lock()
+
+    def emit(**extra):
+        """prints the line once (rank 0), whoever gets here first"""
+        if not emitted.acquire(blocking=False):
+            return
+        if out is not None:
+            out.update(extra)
+            print(json.dumps(out))
+            sys.stdout.flush()
+
+    def give_up(reason):
+        """an extra did not finish: the line goes out without it and the process ends here (the other ranks' guards do the same;
+        a collective that a rank has left cannot be waited for)"""
+        emit(multi_gpu={"error": reason})
+        sys.stderr.write("bench.py: %s\n" % reason)
+        sys.stderr.flush()
+        os._exit(0)
+
+    # ---- N > 1: the other BASELINE multi-GPU lines, untimed extras (every rank takes part in their collectives)
+    multi = None
+    if world > 1 and args.extras != "none" and (default_run or args.extras == "small"):
+        small = args.extras == "small"
+        budget_s = float(os.environ.get("KL_BENCH_EXTRAS_SECONDS", "180"))
+        guard = threading.Timer(budget_s, give_up, args=("the multi-GPU extras did not finish within %.0f s" % budget_s,))
+        guard.daemon = True
+        guard.start()
+
+        try:
+            def run_case(rr, mode, frames_all, h, w, steps):
+                runner = partition_runner(rr, mode, frames_all, h, w)
+                runner()                                      # warm-up (buffers, first touch)
+                rr.synchronize()
+                rr.reset_counters()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    runner()
+                    rr.synchronize()
+                fence()
+                dt = max_over_ranks(time.perf_counter() - t0)
+                rays = sum_over_ranks(rr.counters().rays)
+                # one more step with a wait between render and exchange, to time the exchange by itself
+                tm = {}
+                runner(timing=tm)
+                rr.synchronize()
+                return {"samples_per_s": float(h) * w * frames_all * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                        "mrays_per_s": rays / dt / 1e6, "frames_in_all": frames_all, "frames_per_rank": frames_all if mode == "tiles" else frames_all / world,
+                        "exchange_ms": 1e3 * max_over_ranks(tm.get("exchange_s", 0.0)), "render_ms_rank_max": 1e3 * max_over_ranks(tm.get("render_s", 0.0)),
+                        "rccl_ranks": dist.get_world_size(), "backend": collective, "partition": mode, "image": "%dx%d" % (w, h),
+                        "exchange": ("all-gather of %.1f MB per rank + un-tile" % (h * w * 16 / world / 1e6)) if mode == "tiles"
+                                    else ("all-reduce(sum) of %.1f MB + divide" % (h * w * 16 / 1e6))}
+
+            multi = {"note": "untimed extras (not in `value`): the other BASELINE multi-GPU lines, each timed like the main region (barrier + "
+                             "synchronize on both sides, max over ranks); exchange_ms = the collective and its un-tile / divide alone, from one "
+                             "further step with a wait between render and exchange"}
+            if os.environ.get("KL_BENCH_TEST_FAIL_EXTRAS") == str(rank):      # test hook: this rank leaves the extras
+                raise RuntimeError("requested by KL_BENCH_TEST_FAIL_EXTRAS")
+            # (1) strong scaling of the headline workload: spp frames in all, split over the ranks
+            multi["strong"] = run_case(r, "samples", spp, height, width, args.steps)
+            multi["strong"]["workload"] = "%s, %dx%d, %d spp in all, sample ranges" % (pre["name"], width, height, spp)
+            r.close()
+            r = None
+            # (2) BASELINE configs[3]: the same scene at 4K, 256 spp, image tiles; the packed scene is imported again, not rebuilt
+            w4, h4, spp4 = (3840, 2160, 256) if not small else (2 * width, 2 * height, 2 * spp)
+            r4 = kl.Renderer(w4, h4, device=device)
+            r4.scene_import(scene_block.data_ptr(), scene_block.numel())
+            r4.upload_texture(kl.TEX_HDRI, bg)
+            r4.upload_texture(kl.TEX_ALBEDO, tx)
+            r4.update_params(max_bounces=args.bounces, max_frames=0, trace_primary_per_frame=1)
+            multi["config4_tiles"] = run_case(r4, "tiles", spp4, h4, w4, 1 if not small else 2)
+            multi["config4_tiles"]["workload"] = "%s, %dx%d, %d spp, row bands of %d rows round-robin" % (PRESETS[4]["name"], w4, h4, spp4, args.band_rows)
+            r4.close()
+            scene_block = None
+            # (3) BASELINE configs[4]: 10 M primitives at 4K, 1024 spp in all, sample ranges; one host SAH build on rank 0, broadcast
+            w5, h5, spp5 = (3840, 2160, 1024) if not small else (2 * width, 2 * height, 4 * spp)
+            blobs5, spheres5 = (PRESETS[5]["blobs"], PRESETS[5]["spheres"]) if not small else (3 * blobs, 50)
+            r5 = kl.Renderer(w5, h5, device=device)
+            _, block5, scene5_s = make_scene(r5, blobs5, spheres5, args.tris_per_blob, args.builder)
+            r5.upload_texture(kl.TEX_HDRI, bg)
+            r5.upload_texture(kl.TEX_ALBEDO, tx)
+            r5.update_params(max_bounces=args.bounces, max_frames=0, trace_primary_per_frame=1)
+            b5 = r5.bvh_stats()
+            multi["config5_samples"] = run_case(r5, "samples", spp5, h5, w5, 1 if not small else 2)
+            multi["config5_samples"].update({"workload": "%s, %dx%d, %d spp in all" % (PRESETS[5]["name"], w5, h5, spp5),
+                                             "primitives": int(b5.tris + b5.spheres + b5.quads), "bvh_nodes": int(b5.nodes),
+                                             "scene_seconds_rank0_build_plus_broadcast": round(scene5_s, 2), "packed_scene_mb": round(block5.numel() / 1e6, 1)})
+            r5.close()
+            block5 = None
+
+        except Exception as e:          # noqa: BLE001 -- whatever it was, the timed result must still be reported
+            give_up("the multi-GPU extras failed on rank %d: %s: %s" % (rank, type(e).__name__, e))
+        guard.cancel()
+    cpu = builtin = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        try:
+            cpu = cpu_baseline(scene, (bg, tx), width, height, args.bounces, args.cpu_seconds)
+        except Exception as e:          # noqa: BLE001
+            cpu = {"error": "%s: %s" % (type(e).__name__, e)}
+        if args.extras != "none":
+            try:
+                builtin = builtin_figures(kl, device, (bg, tx))
+            except Exception as e:      # noqa: BLE001
+                builtin = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    emit(cpu_baseline=cpu, builtin=builtin, multi_gpu=multi)
     if r is not None:
         r.close()
     if dist is not None:

@@ -214,3 +214,24 @@ def test_bench_with_two_ranks_on_one_gpu(partition, scaling):
     else:
         assert j["multi_gpu"] is None
     assert "gloo" in j["config"]["partition"]
+
+
+@pytest.mark.parametrize("failing_rank", [0, 1])
+def test_bench_line_survives_a_failed_extra(failing_rank):
+    """The timed result is printed exactly once whatever happens in the untimed multi-GPU extras: a rank that raises there
+    leaves at once (rank 0 after printing the line), the rank left waiting in a collective is released by its time budget."""
+    import json
+    import subprocess
+    import sys
+    port = free_port()
+    env = dict(os.environ, KL_BENCH_BACKEND="gloo", KL_BENCH_TEST_FAIL_EXTRAS=str(failing_rank), KL_BENCH_EXTRAS_SECONDS="15")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--width", "320", "--height", "180", "--spp", "8",
+           "--blobs", "20", "--tris-per-blob", "200", "--skip-kernels", "--skip-shared", "--cpu-seconds", "0", "--extras", "small"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "error" in j["multi_gpu"]
+    assert ("failed on rank 0" in j["multi_gpu"]["error"]) if failing_rank == 0 else ("did not finish within" in j["multi_gpu"]["error"])
