@@ -234,4 +234,8 @@ def test_bench_line_survives_a_failed_extra(failing_rank):
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and "error" in j["multi_gpu"]
-    assert ("failed on rank 0" in j["multi_gpu"]["error"]) if failing_rank == 0 else ("did not finish within" in j["multi_gpu"]["error"])
+    err = j["multi_gpu"]["error"]
+    if failing_rank == 0:
+        assert "failed on rank 0" in err and "KL_BENCH_TEST_FAIL_EXTRAS" in err
+    else:       # rank 0 was left in a collective: its backend reports the lost peer, or its time budget runs out
+        assert "failed on rank 0" in err or "did not finish within" in err
