@@ -429,7 +429,7 @@ class Group:
         devs = (C.c_int32 * len(devices))(*devices)
         rc = lib().kl_group_create(C.byref(self._h), devs, len(devices), split, width, height, band_rows)
         if rc != 0:
-            raise KlError("kl_group_create failed: %s" % lib().kl_status_string(rc).decode())
+            raise KlError("kl_group_create failed: %s (%s)" % (lib().kl_status_string(rc).decode(), (lib().kl_group_last_error(None) or b"").decode()))
         self.width, self.height, self.n = width, height, len(devices)
 
     def _ck(self, rc, what):

@@ -84,6 +84,24 @@ def test_argument_checks_without_gpu():
     n = [C.c_uint32() for _ in range(4)]
     assert L.kl_synth_scene_counts(C.byref(sp), *[C.byref(x) for x in n]) == -1
     assert L.kl_status_string(-4) == b"invalid state"
+    # new entry points refuse null arguments before touching a device
+    assert L.kl_get_stream(None, None) == -1 and L.kl_scene_blob_bytes(None, None) == -1
+    assert L.kl_scene_export(None, None, 0) == -1 and L.kl_scene_import(None, None, 0) == -1
+
+
+def test_group_create_failure_keeps_its_reason():
+    """kl_group_create has no group to hold an error text when it fails: kl_group_last_error(NULL) gives the reason of the
+    last failed create on the calling thread"""
+    L = kl.lib()
+    g = C.c_void_p()
+    devs = (C.c_int32 * 1)(0)
+    assert L.kl_group_create(C.byref(g), devs, 0, kl.SPLIT_TILES, 64, 36, 8) == -1 and not g.value
+    assert L.kl_group_last_error(None) == b"bad argument"
+    # a member that cannot be created (no such device, or no GPU at all here): the member and its reason are named
+    bad = (C.c_int32 * 1)(63)
+    rc = L.kl_group_create(C.byref(g), bad, 1, kl.SPLIT_TILES | kl.EXCHANGE_COPY, 64, 36, 8)
+    assert rc < 0 and not g.value
+    assert L.kl_group_last_error(None).startswith(b"member 0 (device 63)")
 
 
 def test_product_does_not_import_oracle():
