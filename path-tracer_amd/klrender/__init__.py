@@ -224,6 +224,7 @@ class Renderer:
             raise KlError("kl_create failed: %s" % lib().kl_status_string(rc).decode())
         self.width, self.height, self.device = width, height, device
         self.shard = (0, 1, 1)
+        self.accum_mode = ACCUM_MEAN
 
     # -- plumbing
     def _ck(self, rc, what):
@@ -412,6 +413,7 @@ class Renderer:
 
     def set_accum_mode(self, mode):
         self._ck(lib().kl_set_accum_mode(self._h, mode), "kl_set_accum_mode")
+        self.accum_mode = mode
 
     def copy_accum_to_device(self, device_ptr, nbytes):
         self._ck(lib().kl_copy_accum_to_device(self._h, C.c_void_p(device_ptr), nbytes), "kl_copy_accum_to_device")

@@ -87,7 +87,10 @@ def render_tiles(renderer, n_frames, band_rows, first_frame=0, group=None, gathe
     render and of the exchange (all-gather + un-tile) separately, at the price of a wait between the two."""
     import time
     t0 = time.perf_counter()
+    from . import ACCUM_MEAN, ACCUM_SUM
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if renderer.accum_mode == ACCUM_SUM:    # left over from a sample-range render: tiles hold the running mean
+        renderer.set_accum_mode(ACCUM_MEAN)
     if renderer.shard != (rank, world, band_rows):
         renderer.set_shard(rank, world, band_rows)
     else:
@@ -123,6 +126,8 @@ def render_sample_ranges(renderer, n_frames, first_frame=0, group=None, out=None
     t0 = time.perf_counter()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi = partition.frame_range(first_frame, n_frames, rank, world)
+    if renderer.shard[1] != 1:              # left over from an image-tile render: sample ranges cover the whole image
+        renderer.set_shard(0, 1, 1)
     renderer.set_accum_mode(ACCUM_SUM)
     if hi > lo:
         renderer.render_frames(hi - lo, first_frame=lo)
