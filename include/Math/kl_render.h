@@ -104,7 +104,7 @@ typedef struct kl_params {
                                   2: the kernel the scene runs anyway tallies the same per wave (ballot + popcount: about 1 % slower) */
     uint32_t profile_kernels;  /* 1: HIP events around every generate / intersect / shade / accumulate launch, see kl_get_timing */
     uint32_t batch_lanes;      /* batches traced concurrently on separate HIP streams, each with its own queues: 0 = choose
-                                  (two), 1 = one stream, at most 4. The image does not depend on it (batches accumulate in frame order). */
+                                  (one), at most 4. The image does not depend on it (batches accumulate in frame order). */
     uint32_t trace_primary_per_frame; /* 0: the camera ray of a pixel, which is the same in every frame (RawFrame.glsl:436 adds no
                                   jitter at SPP = 1), is traced once per batch and its hit shared by the batch's frames;
                                   1: traced again for every frame, as the shader does. The image is the same either way. */

@@ -180,10 +180,11 @@ uint32_t choose_slots(kl_ctx *c) {
 
 uint32_t choose_lanes(kl_ctx *c) {
     uint32_t n = c->params.batch_lanes;
-    // automatic: two. The stages of a batch want different things (traversal: instruction issue and cache latency;
-    // shade: HBM bandwidth), so two batches in flight fill each other's gaps as well as each other's launch tails
-    // (measured at 1080p: +2.8 % over one lane; three or four lanes bring nothing more).
-    if (n == 0) n = 2u;
+    // automatic: one. Two lanes used to pay (+2.8 %: while one batch drained the tail of a traversal launch or sat in shade's
+    // half-empty second round of blocks, the other filled the CUs). Since shade's grid is made of many small blocks a single
+    // lane is as fast or faster at every batch size (1080p, 4 / 8 / 16 / 32 / 64 frames: 1764 / 1934 / 2010 / 2044 / 2058 against
+    // 1723 / 1912 / 1997 / 2045 / 2033 M samples/s) and holds one set of queues instead of two.
+    if (n == 0) n = 1u;
     return std::min(n, KL_MAX_BATCH_LANES);
 }
 // frames per batch for a call that renders n frames on `lanes` lanes: as many as memory allows (choose_slots), but
