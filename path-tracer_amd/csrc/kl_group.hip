@@ -204,7 +204,29 @@ const char *kl_group_last_error(kl_group *g) { return g ? g->err.c_str() : t_cre
 static kl_status kl_group_upload_scene_body(kl_group *g, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
                                 const kl_material *mt, uint32_t nm) {
     if (!g) return KL_E_INVALID;
-    for (uint32_t k = 0; k < g->n; k++) KLG_CTX(g, k, kl_upload_scene(g->m[k].ctx, s, ns, q, nq, t, nt, mt, nm));
+    // One tree build for the whole group: member 0 builds, the packed scene (kl_scene_export: records, tree, shading records,
+    // flat-quad table as one relocatable block) goes to every other member's GPU by a peer copy, and they import it.
+    KLG_CTX(g, 0, kl_upload_scene(g->m[0].ctx, s, ns, q, nq, t, nt, mt, nm));
+    if (g->n > 1) {
+        size_t bytes = 0;
+        KLG_CTX(g, 0, kl_scene_blob_bytes(g->m[0].ctx, &bytes));
+        struct Block {          // freed on every way out
+            int dev; void *p = nullptr;
+            explicit Block(int d) : dev(d) {}
+            ~Block() { if (p) { (void)hipSetDevice(dev); (void)hipFree(p); } }
+        };
+        Block src(g->m[0].device);
+        KLG_HIP(g, hipSetDevice(src.dev));
+        KLG_HIP(g, hipMalloc(&src.p, bytes));
+        KLG_CTX(g, 0, kl_scene_export(g->m[0].ctx, src.p, bytes));
+        for (uint32_t k = 1; k < g->n; k++) {
+            Block dst(g->m[k].device);
+            KLG_HIP(g, hipSetDevice(dst.dev));
+            KLG_HIP(g, hipMalloc(&dst.p, bytes));
+            KLG_HIP(g, hipMemcpyPeer(dst.p, dst.dev, src.p, src.dev, bytes));
+            KLG_CTX(g, k, kl_scene_import(g->m[k].ctx, dst.p, bytes));
+        }
+    }
     return kl_group_reset(g);
 }
 kl_status kl_group_upload_scene(kl_group *g, const kl_sphere *s, uint32_t ns, const kl_quad *q, uint32_t nq, const kl_tri *t, uint32_t nt,
